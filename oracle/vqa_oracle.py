@@ -1,0 +1,256 @@
+"""CPU oracle for the VqaNet train-step hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, on the CPU, the arithmetic of the reference's hot path
+(OmerShubi/DL_VQA ``models/model.py`` + the loss/metric/optimiser lines of
+``train.py`` / ``utils/train_utils.py``).  It exists so the HIP kernels can be
+checked against an independent implementation on the GPU box, where the
+reference itself cannot travel.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  The product path (``dl_vqa_amd``) never does: it calls the
+HIP kernels through the C ABI and fails loudly when the library is missing.
+
+Parity pin: the reference publishes no tests or golden vectors,
+so the oracle is pinned by fixtures under ``tests/golden/`` that were produced
+by importing the reference's ``models/model.py`` in the build container
+(``tests/golden/make_golden.py``).  ``tests/test_oracle_golden.py`` checks the
+oracle against every one of them.
+
+Every op is written out with basic tensor algebra (conv through ``F.conv2d``
+is the only library contraction; the LSTM is an explicit masked loop rather
+than ``nn.LSTM``) so that the intermediate quantities the HIP path saves for
+backward (pool arg-max, gate activations, attention probabilities) have a
+named counterpart here.  ``dtype=torch.float64`` gives a higher-precision
+reference for error budgeting.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------
+# image encoder  — reference models/model.py:72-84 (ImageNet2)
+# --------------------------------------------------------------------------
+def conv_relu_pool(x: Tensor, w: Tensor, b: Tensor, stride: int = 1) -> Tensor:
+    """Conv2d(k, stride, pad=0) -> ReLU -> MaxPool2d(2,2)  (model.py:80-82)."""
+    y = F.conv2d(x, w, b, stride=stride)
+    y = torch.relu(y)
+    return F.max_pool2d(y, 2, 2)
+
+
+def image_encoder(sd: Dict[str, Tensor], v: Tensor, stride: int = 1,
+                  stages: Optional[dict] = None) -> Tensor:
+    """ImageNet2.forward in eval mode (model.py:79-84; dropout is identity)."""
+    i = 0
+    while f"image.conv{i}.weight" in sd:
+        v = conv_relu_pool(v, sd[f"image.conv{i}.weight"], sd[f"image.conv{i}.bias"], stride)
+        if stages is not None:
+            stages[f"pool{i}"] = v
+        i += 1
+    return v
+
+
+def l2_normalise(v: Tensor) -> Tensor:
+    """v / (||v||_2 over channels + 1e-12)   (model.py:56)."""
+    return v / (v.norm(p=2, dim=1, keepdim=True).expand_as(v) + 1e-12)
+
+
+# --------------------------------------------------------------------------
+# question encoder — reference models/model.py:134-166 (questionNet)
+# --------------------------------------------------------------------------
+def lstm_direction(x: Tensor, q_len: Tensor, w_ih: Tensor, w_hh: Tensor,
+                   b_ih: Tensor, b_hh: Tensor, reverse: bool) -> Tuple[Tensor, Tensor]:
+    """One direction of nn.LSTM over a packed batch, as a masked loop.
+
+    x [B,T,E]; sample b is updated only at steps t < q_len[b]; the reverse
+    direction visits t = len-1 .. 0 per sample, which with masking is the same
+    as visiting t = T-1 .. 0 and skipping t >= len.  Gate order i,f,g,o
+    (torch.nn.LSTM; used by model.py:145-149, packed at model.py:159-162).
+    Returns (h_n, c_n) [B,H].
+    """
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    steps = range(T - 1, -1, -1) if reverse else range(T)
+    for t in steps:
+        gates = x[:, t] @ w_ih.t() + h @ w_hh.t() + b_ih + b_hh
+        i, f, g, o = gates.split(H, dim=1)
+        i, f, o = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o)
+        g = torch.tanh(g)
+        c_new = f * c + i * g
+        h_new = o * torch.tanh(c_new)
+        m = (q_len > t).to(x.dtype).unsqueeze(1)
+        c = m * c_new + (1 - m) * c
+        h = m * h_new + (1 - m) * h
+    return h, c
+
+
+def question_encoder(sd: Dict[str, Tensor], q: Tensor, q_len: Tensor,
+                     bidirectional: bool = True) -> Tensor:
+    """questionNet.forward in eval mode: embedding(pad 0) -> tanh -> LSTM -> c_n.
+
+    Returns [B, 2H] = [c_fwd | c_bwd]  (model.py:164-166: c_n.transpose(0,1).flatten(1)).
+    """
+    emb = sd["text.embedding.weight"]
+    # padding_idx=0 (model.py:138-140): row 0 is read as stored but receives no gradient
+    x = torch.tanh(F.embedding(q, emb, padding_idx=0))       # model.py:155-157
+    outs = []
+    _, c = lstm_direction(x, q_len, sd["text.lstm.weight_ih_l0"], sd["text.lstm.weight_hh_l0"],
+                          sd["text.lstm.bias_ih_l0"], sd["text.lstm.bias_hh_l0"], False)
+    outs.append(c)
+    if bidirectional:
+        _, c = lstm_direction(x, q_len, sd["text.lstm.weight_ih_l0_reverse"],
+                              sd["text.lstm.weight_hh_l0_reverse"],
+                              sd["text.lstm.bias_ih_l0_reverse"],
+                              sd["text.lstm.bias_hh_l0_reverse"], True)
+        outs.append(c)
+    return torch.cat(outs, dim=1)
+
+
+# --------------------------------------------------------------------------
+# attention — reference models/model.py:169-195, 208-231
+# --------------------------------------------------------------------------
+def attention_scores(sd: Dict[str, Tensor], v: Tensor, q: Tensor, do_option: str = "+") -> Tensor:
+    """Attention.forward in eval mode (model.py:183-195).  v [B,C,g,g], q [B,Q] -> [B,G,g,g]."""
+    wv = sd["attention.v_conv.weight"]          # [mid, C, 1, 1], no bias (model.py:173)
+    vv = torch.einsum("bchw,mc->bmhw", v, wv[:, :, 0, 0])
+    qq = q @ sd["attention.q_lin.weight"].t() + sd["attention.q_lin.bias"]
+    qq = qq[:, :, None, None].expand_as(vv)     # tile_question_over_image (model.py:224-231)
+    if do_option == "*":
+        x = torch.relu(vv * qq)
+    elif do_option == "+":
+        x = torch.relu(vv + qq)
+    elif do_option == "|":
+        x = torch.relu(torch.cat([vv, qq], dim=1))
+    else:
+        raise ValueError(do_option)
+    wx = sd["attention.x_conv.weight"][:, :, 0, 0]
+    return torch.einsum("bmhw,gm->bghw", x, wx) + sd["attention.x_conv.bias"][None, :, None, None]
+
+
+def image_question_attention(v: Tensor, att: Tensor) -> Tuple[Tensor, Tensor]:
+    """softmax over positions per glimpse, weighted sum of v (model.py:208-221).
+
+    Returns ([B, G*C] glimpse-major, probabilities [B,G,P])."""
+    B, C = v.shape[:2]
+    G = att.shape[1]
+    vf = v.reshape(B, C, -1)
+    p = torch.softmax(att.reshape(B, G, -1), dim=-1)
+    out = torch.einsum("bgp,bcp->bgc", p, vf).reshape(B, G * C)
+    return out, p
+
+
+def classifier(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """Classifier in eval mode: Linear -> ReLU -> Linear (model.py:198-205)."""
+    h = torch.relu(x @ sd["classifier.lin1.weight"].t() + sd["classifier.lin1.bias"])
+    return h @ sd["classifier.lin2.weight"].t() + sd["classifier.lin2.bias"]
+
+
+def vqa_forward(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: Tensor,
+                stages: Optional[dict] = None) -> Tensor:
+    """VqaNet.forward in eval mode (model.py:53-67). Returns logits [B, max_answers]."""
+    img = image_encoder(sd, v, cfg["image"]["stride"], stages)
+    vn = l2_normalise(img)
+    qf = question_encoder(sd, q, q_len, cfg["text"]["bidirectional"])
+    att = attention_scores(sd, vn, qf, cfg["attention"]["do_option"])
+    wv, probs = image_question_attention(vn, att)
+    logits = classifier(sd, torch.cat([wv, qf], dim=1))
+    if stages is not None:
+        stages.update(image=img, vnorm=vn, question=qf, attention=att, probs=probs,
+                      weighted=wv, logits=logits)
+    return logits
+
+
+# --------------------------------------------------------------------------
+# loss / metric — reference train.py:189-207, utils/train_utils.py:12-25
+# --------------------------------------------------------------------------
+def soft_ce_loss(logits: Tensor, a_indices: Tensor, a_values: Tensor) -> Tensor:
+    """loss = sum_{b,k: a_idx[b,k]!=0} -log_softmax(logits)[b, a_idx[b,k]-1] * a_val[b,k]/10 / B.
+
+    train.py:190-206: answers are 1-based, 0 is padding; counts are divided by 10.
+    """
+    nll = -torch.log_softmax(logits, dim=1)
+    B = logits.shape[0]
+    mask = a_indices != 0
+    idx = (a_indices - 1).clamp(min=0)
+    picked = torch.gather(nll, 1, idx)
+    w = (a_values.to(logits.dtype) / 10.0) * mask.to(logits.dtype)
+    return (picked * w).sum() / B
+
+
+def batch_accuracy(logits: Tensor, a_indices: Tensor, a_values: Tensor) -> Tensor:
+    """sum_b min(1, 0.3 * count of the arg-max answer)   (train_utils.py:12-25)."""
+    pred = logits.argmax(dim=1, keepdim=True) + 1          # back to 1-based
+    hit = (a_indices == pred) & (a_indices != 0)
+    agreeing = (a_values * hit).sum(dim=1).to(torch.float32)
+    return (agreeing * 0.3).clamp(max=1).sum()
+
+
+def learning_rate(initial_lr: float, iteration: int, halflife: int = 50000) -> float:
+    """train.py:31-35: lr = lr0 * 0.5 ** (iteration / 50000)."""
+    return initial_lr * 0.5 ** (float(iteration) / halflife)
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """torch.optim.Adam defaults, no weight decay, no amsgrad (train.py:55,80). In place."""
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# --------------------------------------------------------------------------
+# whole train step on the CPU (used as bench.py's cpu_baseline "port")
+# --------------------------------------------------------------------------
+def loss_and_grads(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: Tensor,
+                   a_indices: Tensor, a_values: Tensor,
+                   loss_scale_batch: Optional[int] = None
+                   ) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
+    """Forward + soft-CE + backward by autograd over the restated ops.
+
+    ``loss_scale_batch`` overrides the divisor B (used by the data-parallel
+    tests, where each rank divides by the GLOBAL batch)."""
+    params = {k: t.detach().clone().requires_grad_(True) for k, t in sd.items()}
+    logits = vqa_forward(params, cfg, v, q, q_len)
+    loss = soft_ce_loss(logits, a_indices, a_values)
+    if loss_scale_batch is not None:
+        loss = loss * (logits.shape[0] / float(loss_scale_batch))
+    grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    out = {}
+    for (k, p), g in zip(params.items(), grads):
+        out[k] = torch.zeros_like(p) if g is None else g
+    return logits.detach(), loss.detach(), out
+
+
+def synthetic_batch(B: int, S: int, T: int, V: int, A: int, seed: int = 1, full_len: bool = False,
+                    kmax: int = 3):
+    """Synthetic 7-tuple in the dataset's layout (data_preprocessing.py:74-87), SURVEY §8d.
+
+    v ~ N(0,1) f32 [B,3,S,S]; q uniform in [1,V) zero-padded past q_len; 1..kmax unique 1-based
+    answers per sample with counts summing to <= 10."""
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(B, 3, S, S, generator=g)
+    q_len = torch.full((B,), T, dtype=torch.int64) if full_len else \
+        torch.randint(1, T + 1, (B,), generator=g)
+    q = torch.randint(1, V, (B, T), generator=g)
+    q = q * (torch.arange(T)[None, :] < q_len[:, None])
+    a_len = torch.randint(1, kmax + 1, (B,), generator=g)
+    a_idx = torch.zeros(B, kmax, dtype=torch.int64)
+    a_val = torch.zeros(B, kmax, dtype=torch.int64)
+    for b in range(B):
+        k = int(a_len[b])
+        idx = torch.randperm(A, generator=g)[:k] + 1
+        cnt = torch.randint(1, 4, (k,), generator=g)
+        a_idx[b, :k] = idx
+        a_val[b, :k] = cnt
+    return v, q, a_idx, a_val, a_len, torch.arange(B), q_len

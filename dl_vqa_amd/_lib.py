@@ -1,0 +1,100 @@
+"""ctypes binding of libvqa_hip.so (include/vqa_hip.h). No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqa_hip.so")
+
+f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+u8p = C.c_void_p
+i64p = C.c_void_p
+i32, i64, f32, u64, vp = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/vqa_hip.h one to one
+PROTOTYPES = {
+    "vqa_abi_version": (i32, []),
+    "vqa_last_error": (C.c_char_p, []),
+    "vqa_device_ok": (i32, []),
+    "vqa_prof_arm": (i32, [i32, i32]),
+    "vqa_prof_read": (i32, [C.POINTER(i32), C.POINTER(f32)]),
+    "vqa_gemm_workspace_bytes": (i64, [i32, i32, i32]),
+    "vqa_gemm": (i32, [f32p, i64, i32, f32p, i64, i32, f32p, i64, i32, i32, i32, f32p, f32p,
+                       f32p, i64, i32, i32, i32, i32, f32p, i64, i32, vp]),
+    "vqa_nchw_to_nhwc4": (i32, [f32p, f32p, i32, i32, i32, i32, vp]),
+    "vqa_conv_pack_weights": (i32, [f32p, f32p, f32p, i32, i32, i32, vp]),
+    "vqa_conv3x3_relu_pool_fwd": (i32, [f32p, f32p, f32p, f32p, u8p, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "vqa_conv3x3_dgrad": (i32, [f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "vqa_conv3x3_wgrad_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
+    "vqa_conv3x3_wgrad": (i32, [f32p, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32,
+                                f32p, i64, i32, vp]),
+    "vqa_dropout": (i32, [f32p, f32p, i64, f32, u64, vp]),
+    "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp]),
+    "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, f32, u64, vp]),
+    "vqa_embed_tanh_fwd": (i32, [i64p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
+    "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
+    "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
+    "vqa_lstm_cell_bwd": (i32, [f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, i32, i32, vp]),
+    "vqa_att_score_fwd": (i32, [f32p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
+    "vqa_att_row_splits": (i32, [i32]),
+    "vqa_att_score_bwd": (i32, [f32p, f32p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
+    "vqa_att_apply_fwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, i32, i32, i32, vp]),
+    "vqa_att_apply_bwd": (i32, [f32p, i64, f32p, f32p, f32p, f32p, i32, i32, i32, i32, vp]),
+    "vqa_softce_fwd_bwd": (i32, [f32p, i64, i64p, i64p, i32, i32, i32, f32, f32p, f32p, f32p, i64, vp]),
+    "vqa_colsum_workspace_bytes": (i64, [i64, i32]),
+    "vqa_colsum": (i32, [f32p, i64, u8p, i64, i32, f32p, i32, f32p, i64, vp]),
+    "vqa_sum_bgp": (i32, [f32p, f32p, i32, i32, i32, vp]),
+    "vqa_sum_parts": (i32, [f32p, f32p, i32, i32, i32, vp]),
+    "vqa_relu_drop_bwd": (i32, [f32p, f32p, f32p, i64, f32, u64, vp]),
+    "vqa_add": (i32, [f32p, f32p, f32p, i64, vp]),
+    "vqa_adam": (i32, [f32p, f32p, f32p, f32p, i64, f32, f32, f32, f32, i32, f32, vp]),
+}
+
+K_GEMM, K_CONV_FWD, K_CONV_DGRAD, K_CONV_WGRAD = 0, 1, 2, 3
+
+
+class VqaHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libvqa_hip.so and attach prototypes. Raises if the library is absent (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VqaHipError(
+            f"{LIB_PATH} not found: build it with `python -m dl_vqa_amd.build` "
+            "(the HIP extension is mandatory; there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vqa_abi_version() != 1:
+        raise VqaHipError("libvqa_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point; raise VqaHipError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise VqaHipError(f"{name} failed ({rc}): {lib.vqa_last_error().decode()}")

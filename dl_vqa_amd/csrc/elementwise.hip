@@ -1,0 +1,686 @@
+// Memory-bound stages of the VQA hot path: dropout, L2-norm, embedding+tanh, LSTM cell, attention
+// score / softmax / weighted sum, soft-target cross entropy, reductions, Adam.
+// All are HBM-bound streaming kernels: 16-byte per-lane accesses, wave64 shuffles for reductions.
+#include "common.hpp"
+
+namespace vqa {
+
+static inline int grid_for(int64_t n, int per_block, int cap = 8192) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ dropout
+__global__ void dropout_kernel(const float* x, float* y, int64_t n, float p, float inv_keep, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = x[i] * drop_scale(seed, (uint64_t)i, p, inv_keep);
+}
+
+// ------------------------------------------------------------------ L2 norm (+ image dropout)
+// one wave per row of C floats
+__global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p,
+                                  float inv_keep, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nch = C >> 2;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float4* src = reinterpret_cast<const float4*>(pooled + r * C);
+    float ss = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+      float4 u = src[c];
+      if (p > 0.f) {
+        const uint64_t e = (uint64_t)r * C + 4 * c;
+        u.x *= drop_scale(seed, e, p, inv_keep); u.y *= drop_scale(seed, e + 1, p, inv_keep);
+        u.z *= drop_scale(seed, e + 2, p, inv_keep); u.w *= drop_scale(seed, e + 3, p, inv_keep);
+      }
+      ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+    }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    const float inv = 1.0f / (nrm + 1e-12f);
+    if (lane == 0) norm[r] = nrm;
+    float4* dst = reinterpret_cast<float4*>(vn + r * C);
+    for (int c = lane; c < nch; c += 64) {
+      float4 u = src[c];
+      if (p > 0.f) {
+        const uint64_t e = (uint64_t)r * C + 4 * c;
+        u.x *= drop_scale(seed, e, p, inv_keep); u.y *= drop_scale(seed, e + 1, p, inv_keep);
+        u.z *= drop_scale(seed, e + 2, p, inv_keep); u.w *= drop_scale(seed, e + 3, p, inv_keep);
+      }
+      dst[c] = make_float4(u.x * inv, u.y * inv, u.z * inv, u.w * inv);
+    }
+  }
+}
+
+__global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float* norm, float* dpooled,
+                                  int64_t rows, int C, float p, float inv_keep, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nch = C >> 2;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float4* g = reinterpret_cast<const float4*>(dvn + r * C);
+    const float4* v = reinterpret_cast<const float4*>(vn + r * C);
+    float dot = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+      const float4 a = g[c], b = v[c];
+      dot += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    dot = wave_sum(dot);
+    const float n = norm[r];
+    const float inv = 1.0f / (n + 1e-12f);
+    const float k = n > 0.f ? dot * (n + 1e-12f) / n : 0.f;
+    float4* dst = reinterpret_cast<float4*>(dpooled + r * C);
+    for (int c = lane; c < nch; c += 64) {
+      const float4 a = g[c], b = v[c];
+      float4 d = make_float4((a.x - b.x * k) * inv, (a.y - b.y * k) * inv, (a.z - b.z * k) * inv, (a.w - b.w * k) * inv);
+      if (p > 0.f) {
+        const uint64_t e = (uint64_t)r * C + 4 * c;
+        d.x *= drop_scale(seed, e, p, inv_keep); d.y *= drop_scale(seed, e + 1, p, inv_keep);
+        d.z *= drop_scale(seed, e + 2, p, inv_keep); d.w *= drop_scale(seed, e + 3, p, inv_keep);
+      }
+      dst[c] = d;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ embedding + dropout + tanh
+__global__ void embed_tanh_fwd_kernel(const int64_t* q, const float* emb, float* x, int B, int T, int E, int V,
+                                      float p, float inv_keep, uint64_t seed) {
+  const int64_t total = (int64_t)T * B * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E);
+    const int64_t tb = i / E;
+    const int b = (int)(tb % B), t = (int)(tb / B);
+    int64_t tok = q[(int64_t)b * T + t];
+    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+    float v = emb[tok * E + e];
+    if (p > 0.f) v *= drop_scale(seed, ((uint64_t)b * T + t) * E + e, p, inv_keep);
+    x[i] = tanhf(v);
+  }
+}
+
+__global__ void embed_tanh_bwd_kernel(const int64_t* q, const float* x, const float* dx, float* demb, int B, int T,
+                                      int E, int V, float p, float inv_keep, uint64_t seed) {
+  const int64_t total = (int64_t)T * B * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E);
+    const int64_t tb = i / E;
+    const int b = (int)(tb % B), t = (int)(tb / B);
+    const int64_t tok = q[(int64_t)b * T + t];
+    if (tok <= 0 || tok >= V) continue;  // padding_idx = 0 receives no gradient
+    const float xv = x[i];
+    float g = dx[i] * (1.f - xv * xv);
+    if (p > 0.f) g *= drop_scale(seed, ((uint64_t)b * T + t) * E + e, p, inv_keep);
+    atomicAdd(demb + tok * E + e, g);
+  }
+}
+
+// ------------------------------------------------------------------ LSTM cell
+__global__ void lstm_cell_fwd_kernel(const float* xg, const float* hg, const float* c_in, const float* h_in,
+                                     const int64_t* q_len, int t, float* gates, float* c_out, float* h_out,
+                                     float* c_final, int64_t cf_ld, int B, int H) {
+  const int64_t total = (int64_t)B * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / H), j = (int)(i - (int64_t)b * H);
+    const int64_t g0 = (int64_t)b * 4 * H + j;
+    const float cp = c_in[i], hp = h_in[i];
+    float cn = cp, hn = hp;
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+    if ((int64_t)t < q_len[b]) {
+      gi = sigmoidf_(xg[g0] + hg[g0]);
+      gf = sigmoidf_(xg[g0 + H] + hg[g0 + H]);
+      gg = tanhf(xg[g0 + 2 * H] + hg[g0 + 2 * H]);
+      go = sigmoidf_(xg[g0 + 3 * H] + hg[g0 + 3 * H]);
+      cn = gf * cp + gi * gg;
+      hn = go * tanhf(cn);
+    }
+    gates[g0] = gi; gates[g0 + H] = gf; gates[g0 + 2 * H] = gg; gates[g0 + 3 * H] = go;
+    c_out[i] = cn; h_out[i] = hn;
+    if (c_final) c_final[(int64_t)b * cf_ld + j] = cn;
+  }
+}
+
+__global__ void lstm_cell_bwd_kernel(const float* gates, const float* c_in, const float* c_out,
+                                     const int64_t* q_len, int t, float* dh, float* dc, float* dgates, int B, int H) {
+  const int64_t total = (int64_t)B * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / H), j = (int)(i - (int64_t)b * H);
+    const int64_t g0 = (int64_t)b * 4 * H + j;
+    float di = 0.f, df = 0.f, dg = 0.f, dgo = 0.f;
+    if ((int64_t)t < q_len[b]) {
+      const float gi = gates[g0], gf = gates[g0 + H], gg = gates[g0 + 2 * H], go = gates[g0 + 3 * H];
+      const float tc = tanhf(c_out[i]);
+      const float dhv = dh[i];
+      const float dct = dc[i] + dhv * go * (1.f - tc * tc);
+      di = dct * gg * gi * (1.f - gi);
+      df = dct * c_in[i] * gf * (1.f - gf);
+      dg = dct * gi * (1.f - gg * gg);
+      dgo = dhv * tc * go * (1.f - go);
+      dc[i] = dct * gf;
+      dh[i] = 0.f;
+    }
+    dgates[g0] = di; dgates[g0 + H] = df; dgates[g0 + 2 * H] = dg; dgates[g0 + 3 * H] = dgo;
+  }
+}
+
+// ------------------------------------------------------------------ attention score (x_conv)
+template <int G>
+__global__ void att_score_fwd_kernel(const float* xs, const float* wx, const float* bx, float* score, int64_t M,
+                                     int P, int mid, float p, float inv_keep, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nch = mid >> 2;
+  for (int64_t m = wave; m < M; m += nwaves) {
+    const float4* row = reinterpret_cast<const float4*>(xs + m * mid);
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+      float4 x = row[c];
+      if (p > 0.f) {
+        const uint64_t e = (uint64_t)m * mid + 4 * c;
+        x.x *= drop_scale(seed, e, p, inv_keep); x.y *= drop_scale(seed, e + 1, p, inv_keep);
+        x.z *= drop_scale(seed, e + 2, p, inv_keep); x.w *= drop_scale(seed, e + 3, p, inv_keep);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 w = reinterpret_cast<const float4*>(wx + (int64_t)g * mid)[c];
+        acc[g] += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+      }
+    }
+    const int64_t b = m / P;
+    const int pp = (int)(m - b * P);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float v = wave_sum(acc[g]);
+      if (lane == 0) score[(b * G + g) * P + pp] = v + bx[g];
+    }
+  }
+}
+
+// grid (B, RS); thread -> float4 column chunks; loops rows of its split
+template <int G>
+__global__ void att_score_bwd_kernel(const float* dscore, const float* wx, float* xs, float* dwx_part,
+                                     float* dq_part, int P, int mid, int RS, float p, float inv_keep, uint64_t seed) {
+  const int b = blockIdx.x, rs = blockIdx.y;
+  const int rows_per = (P + RS - 1) / RS;
+  const int p0 = rs * rows_per, p1 = min(P, p0 + rows_per);
+  const int nch = mid >> 2;
+  const int64_t part = (int64_t)b * RS + rs;
+  for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+    float4 w[G], dw[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      w[g] = reinterpret_cast<const float4*>(wx + (int64_t)g * mid)[c];
+      dw[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pp = p0; pp < p1; ++pp) {
+      const int64_t m = (int64_t)b * P + pp;
+      float4* xp = reinterpret_cast<float4*>(xs + m * mid) + c;
+      const float4 x = *xp;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (p > 0.f) {
+        const uint64_t e = (uint64_t)m * mid + 4 * c;
+        sc.x = drop_scale(seed, e, p, inv_keep); sc.y = drop_scale(seed, e + 1, p, inv_keep);
+        sc.z = drop_scale(seed, e + 2, p, inv_keep); sc.w = drop_scale(seed, e + 3, p, inv_keep);
+      }
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float ds = dscore[((int64_t)b * G + g) * P + pp];
+        t.x += ds * w[g].x; t.y += ds * w[g].y; t.z += ds * w[g].z; t.w += ds * w[g].w;
+        dw[g].x += ds * x.x * sc.x; dw[g].y += ds * x.y * sc.y; dw[g].z += ds * x.z * sc.z; dw[g].w += ds * x.w * sc.w;
+      }
+      float4 d;
+      d.x = x.x > 0.f ? t.x * sc.x : 0.f; d.y = x.y > 0.f ? t.y * sc.y : 0.f;
+      d.z = x.z > 0.f ? t.z * sc.z : 0.f; d.w = x.w > 0.f ? t.w * sc.w : 0.f;
+      *xp = d;
+      dq.x += d.x; dq.y += d.y; dq.z += d.z; dq.w += d.w;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) reinterpret_cast<float4*>(dwx_part + (part * G + g) * mid)[c] = dw[g];
+    reinterpret_cast<float4*>(dq_part + part * mid)[c] = dq;
+  }
+}
+
+// ------------------------------------------------------------------ softmax over positions + weighted sum
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+
+// grid (B, ceil(C/64)), 256 threads = 4 position groups x 64 channels; dynamic LDS: G*P + 16 + 4*G*64 floats
+template <int G>
+__global__ void att_apply_fwd_kernel(const float* score, const float* vn, float* probs, float* out,
+                                     int64_t out_ld, int P, int C) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* pr = sm;            // [G][P]
+  float* red = sm + G * P;   // [16]
+  float* part = red + 16;    // [4][G][64]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int g = 0; g < G; ++g) {
+    const float* s = score + ((int64_t)b * G + g) * P;
+    float mx = -INFINITY;
+    for (int i = tid; i < P; i += blockDim.x) mx = fmaxf(mx, s[i]);
+    mx = block_reduce(mx, red, true);
+    float sum = 0.f;
+    for (int i = tid; i < P; i += blockDim.x) { const float e = expf(s[i] - mx); pr[g * P + i] = e; sum += e; }
+    sum = block_reduce(sum, red, false);
+    const float inv = 1.f / sum;
+    for (int i = tid; i < P; i += blockDim.x) {
+      const float v = pr[g * P + i] * inv;
+      pr[g * P + i] = v;
+      if (blockIdx.y == 0) probs[((int64_t)b * G + g) * P + i] = v;
+    }
+  }
+  __syncthreads();
+  const int cl = tid & 63, pg = tid >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  float acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = 0.f;
+  if (c < C) {
+    const float* vb = vn + (int64_t)b * P * C + c;
+    for (int i = pg; i < P; i += 4) {
+      const float v = vb[(int64_t)i * C];
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] += pr[g * P + i] * v;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) part[(pg * G + g) * 64 + cl] = acc[g];
+  __syncthreads();
+  if (pg == 0 && c < C) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float v = part[g * 64 + cl] + part[(G + g) * 64 + cl] + part[(2 * G + g) * 64 + cl] + part[(3 * G + g) * 64 + cl];
+      out[(int64_t)b * out_ld + g * C + c] = v;
+    }
+  }
+}
+
+// pass 1: one wave per (b,p): dprob -> dscore buffer, dvn row written
+template <int G>
+__global__ void att_apply_bwd_rows_kernel(const float* dout, int64_t dout_ld, const float* probs, const float* vn,
+                                          float* dprob, float* dvn, int64_t M, int P, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int nch = C >> 2;
+  for (int64_t m = wave; m < M; m += nwaves) {
+    const int64_t b = m / P;
+    const int pp = (int)(m - b * P);
+    float pr[G], acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { pr[g] = probs[(b * G + g) * P + pp]; acc[g] = 0.f; }
+    const float4* v = reinterpret_cast<const float4*>(vn + m * C);
+    float4* d = reinterpret_cast<float4*>(dvn + m * C);
+    for (int c = lane; c < nch; c += 64) {
+      const float4 x = v[c];
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 go = reinterpret_cast<const float4*>(dout + b * dout_ld + (int64_t)g * C)[c];
+        acc[g] += x.x * go.x + x.y * go.y + x.z * go.z + x.w * go.w;
+        o.x += pr[g] * go.x; o.y += pr[g] * go.y; o.z += pr[g] * go.z; o.w += pr[g] * go.w;
+      }
+      d[c] = o;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float s = wave_sum(acc[g]);
+      if (lane == 0) dprob[(b * G + g) * P + pp] = s;
+    }
+  }
+}
+// pass 2: block per (b,g): dscore = probs * (dprob - sum_p probs*dprob), in place on dprob
+__global__ void softmax_bwd_kernel(const float* probs, float* dscore, int P) {
+  __shared__ float red[16];
+  const int64_t base = (int64_t)blockIdx.x * P;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) s += probs[base + i] * dscore[base + i];
+  s = block_reduce(s, red, false);
+  for (int i = threadIdx.x; i < P; i += blockDim.x) dscore[base + i] = probs[base + i] * (dscore[base + i] - s);
+}
+
+// ------------------------------------------------------------------ soft-target CE + VQA score
+__global__ void softce_kernel(const float* logits, int64_t ld, const int64_t* a_idx, const int64_t* a_val, int kmax,
+                              int A, float inv_batch, float* loss_rows, float* score_rows, float* dlogits, int64_t dld) {
+  __shared__ float red[16];
+  __shared__ int redi[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* row = logits + (int64_t)b * ld;
+  float mx = -INFINITY;
+  int am = 0x7fffffff;
+  for (int i = tid; i < A; i += blockDim.x) { const float v = row[i]; if (v > mx) { mx = v; am = i; } }
+  // arg-max with smallest-index tie break (torch.max returns the first maximal element)
+  {
+    const int lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(mx, o, 64);
+      const int oi = __shfl_xor(am, o, 64);
+      if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+    }
+    if (lane == 0) { red[w] = mx; redi[w] = am; }
+    __syncthreads();
+    mx = red[0]; am = redi[0];
+    for (int i = 1; i < nw; ++i) if (red[i] > mx || (red[i] == mx && redi[i] < am)) { mx = red[i]; am = redi[i]; }
+  }
+  float sum = 0.f;
+  for (int i = tid; i < A; i += blockDim.x) sum += expf(row[i] - mx);
+  sum = block_reduce(sum, red, false);
+  const float lse = mx + logf(sum);
+  float wsum = 0.f, loss = 0.f, agree = 0.f;
+  for (int k = 0; k < kmax; ++k) {
+    const int64_t idx = a_idx[(int64_t)b * kmax + k];
+    if (idx <= 0 || idx > A) continue;
+    const float w = (float)a_val[(int64_t)b * kmax + k] / 10.0f;
+    wsum += w;
+    loss += w * (lse - row[idx - 1]);
+    if ((int)(idx - 1) == am) agree = (float)a_val[(int64_t)b * kmax + k];
+  }
+  if (tid == 0) {
+    loss_rows[b] = loss * inv_batch;
+    score_rows[b] = fminf(agree * 0.3f, 1.0f);
+  }
+  if (dlogits) {
+    float* d = dlogits + (int64_t)b * dld;
+    const float invs = 1.f / sum;
+    for (int i = tid; i < A; i += blockDim.x) {
+      float g = wsum * expf(row[i] - mx) * invs;
+      for (int k = 0; k < kmax; ++k)
+        if (a_idx[(int64_t)b * kmax + k] == (int64_t)i + 1) g -= (float)a_val[(int64_t)b * kmax + k] / 10.0f;
+      d[i] = g * inv_batch;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ column sums (two stage, deterministic)
+// stage 1: grid (ceil(cols/64), splits); 256 threads = 4 row lanes x 64 columns
+__global__ void colsum_stage1(const float* x, int64_t ld, const uint8_t* mask, int64_t rows, int cols,
+                              int64_t rows_per, float* slab) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
+  float acc = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float v = x[r * ld + c];
+      if (!mask || mask[r * cols + c] != 4) acc += v;
+    }
+  part[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < cols) slab[(int64_t)blockIdx.y * cols + c] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
+}
+__global__ void colsum_stage2(const float* slab, int splits, int cols, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float v = 0.f;
+  for (int s = 0; s < splits; ++s) v += slab[(int64_t)s * cols + c];
+  out[c] = accumulate ? out[c] + v : v;
+}
+
+static void colsum_plan(int64_t rows, int cols, int* splits, int64_t* rows_per) {
+  const int ctiles = (cols + 63) / 64;
+  int64_t s = (1024 + ctiles - 1) / ctiles;          // aim for ~1024 workgroups
+  const int64_t max_s = (rows + 63) / 64;            // at least 64 rows per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  *rows_per = (rows + s - 1) / s;
+  *splits = (int)((rows + *rows_per - 1) / *rows_per);
+}
+int64_t colsum_ws_bytes(int64_t rows, int cols) {
+  int splits; int64_t rp;
+  colsum_plan(rows, cols, &splits, &rp);
+  return (int64_t)splits * cols * 4;
+}
+int colsum_launch(const float* x, int64_t ld, const uint8_t* mask, int64_t rows, int cols, float* out,
+                  int accumulate, float* ws, int64_t ws_bytes, hipStream_t s) {
+  int splits; int64_t rp;
+  colsum_plan(rows, cols, &splits, &rp);
+  if (!ws || ws_bytes < (int64_t)splits * cols * 4) {
+    set_error("colsum: workspace %lld < %lld", (long long)ws_bytes, (long long)splits * cols * 4);
+    return VQA_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(colsum_stage1, dim3((cols + 63) / 64, splits), dim3(256), 0, s, x, ld, mask, rows, cols, rp, ws);
+  int rc = check_hip(hipGetLastError(), "colsum_stage1 launch");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_stage2, dim3((cols + 255) / 256), dim3(256), 0, s, ws, splits, cols, out, accumulate);
+  return check_hip(hipGetLastError(), "colsum_stage2 launch");
+}
+
+__global__ void sum_bgp_kernel(const float* x, float* out, int B, int G, int P) {
+  __shared__ float red[16];
+  const int g = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int i = threadIdx.x; i < P; i += blockDim.x) s += x[((int64_t)b * G + g) * P + i];
+  s = block_reduce(s, red, false);
+  if (threadIdx.x == 0) out[g] = s;
+}
+
+// out[b][n] = sum_r part[(b*parts + r)*cols + n]
+__global__ void sum_parts_kernel(const float* part, float* out, int parts, int cols) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float v = 0.f;
+  for (int r = 0; r < parts; ++r) v += part[((int64_t)b * parts + r) * cols + c];
+  out[(int64_t)b * cols + c] = v;
+}
+
+__global__ void relu_drop_bwd_kernel(const float* y, const float* dy, float* dx, int64_t n, float p, float inv_keep,
+                                     uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float g = y[i] > 0.f ? dy[i] : 0.f;
+    if (p > 0.f) g *= drop_scale(seed, (uint64_t)i, p, inv_keep);
+    dx[i] = g;
+  }
+}
+
+__global__ void add_kernel(const float* a, const float* b, float* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a[i] + b[i];
+}
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1,
+                            float beta2, float eps, float inv_sqrt_bc2, float grad_scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gr = g[i] * grad_scale;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+#define STREAM ((hipStream_t)stream)
+#define KEEP(p) ((p) > 0.f ? 1.0f / (1.0f - (p)) : 1.0f)
+
+extern "C" {
+
+int vqa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa_stream_t stream) {
+  VQA_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f, "vqa_dropout: bad args");
+  if (n == 0) return VQA_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, x, y, n, p, KEEP(p), seed);
+  return check_hip(hipGetLastError(), "dropout launch");
+}
+
+int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p, uint64_t seed,
+                   vqa_stream_t stream) {
+  VQA_REQUIRE(pooled && vn && norm && rows > 0 && C > 0 && C % 4 == 0, "vqa_l2norm_fwd: bad args (C=%d)", C);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, pooled, vn, norm, rows, C, p,
+                     KEEP(p), seed);
+  return check_hip(hipGetLastError(), "l2norm_fwd launch");
+}
+
+int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, float* dpooled, int64_t rows, int C,
+                   float p, uint64_t seed, vqa_stream_t stream) {
+  VQA_REQUIRE(dvn && vn && norm && dpooled && rows > 0 && C % 4 == 0, "vqa_l2norm_bwd: bad args");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
+                     C, p, KEEP(p), seed);
+  return check_hip(hipGetLastError(), "l2norm_bwd launch");
+}
+
+int vqa_embed_tanh_fwd(const int64_t* q, const float* emb, float* x, int B, int T, int E, int V, float p,
+                       uint64_t seed, vqa_stream_t stream) {
+  VQA_REQUIRE(q && emb && x && B > 0 && T > 0 && E > 0 && V > 0, "vqa_embed_tanh_fwd: bad args");
+  hipLaunchKernelGGL(embed_tanh_fwd_kernel, dim3(grid_for((int64_t)B * T * E, 256)), dim3(256), 0, STREAM, q, emb, x,
+                     B, T, E, V, p, KEEP(p), seed);
+  return check_hip(hipGetLastError(), "embed_tanh_fwd launch");
+}
+
+int vqa_embed_tanh_bwd(const int64_t* q, const float* x, const float* dx, float* demb, int B, int T, int E, int V,
+                       float p, uint64_t seed, vqa_stream_t stream) {
+  VQA_REQUIRE(q && x && dx && demb, "vqa_embed_tanh_bwd: null pointer");
+  hipLaunchKernelGGL(embed_tanh_bwd_kernel, dim3(grid_for((int64_t)B * T * E, 256)), dim3(256), 0, STREAM, q, x, dx,
+                     demb, B, T, E, V, p, KEEP(p), seed);
+  return check_hip(hipGetLastError(), "embed_tanh_bwd launch");
+}
+
+int vqa_lstm_cell_fwd(const float* xg, const float* hg, const float* c_in, const float* h_in, const int64_t* q_len,
+                      int t, float* gates, float* c_out, float* h_out, float* c_final, int64_t cf_ld, int B, int H,
+                      vqa_stream_t stream) {
+  VQA_REQUIRE(xg && hg && c_in && h_in && q_len && gates && c_out && h_out, "vqa_lstm_cell_fwd: null pointer");
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((int64_t)B * H, 256)), dim3(256), 0, STREAM, xg, hg, c_in,
+                     h_in, q_len, t, gates, c_out, h_out, c_final, cf_ld, B, H);
+  return check_hip(hipGetLastError(), "lstm_cell_fwd launch");
+}
+
+int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out, const int64_t* q_len, int t,
+                      float* dh, float* dc, float* dgates, int B, int H, vqa_stream_t stream) {
+  VQA_REQUIRE(gates && c_in && c_out && q_len && dh && dc && dgates, "vqa_lstm_cell_bwd: null pointer");
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((int64_t)B * H, 256)), dim3(256), 0, STREAM, gates, c_in,
+                     c_out, q_len, t, dh, dc, dgates, B, H);
+  return check_hip(hipGetLastError(), "lstm_cell_bwd launch");
+}
+
+#define DISPATCH_G(G, ...)                                         \
+  switch (G) {                                                     \
+    case 1: { constexpr int kG = 1; __VA_ARGS__; } break;          \
+    case 2: { constexpr int kG = 2; __VA_ARGS__; } break;          \
+    case 3: { constexpr int kG = 3; __VA_ARGS__; } break;          \
+    case 4: { constexpr int kG = 4; __VA_ARGS__; } break;          \
+    default: set_error("glimpses=%d unsupported (1..4)", G); return VQA_ERR_INVALID; \
+  }
+
+int vqa_att_score_fwd(const float* xs, const float* wx, const float* bx, float* score, int B, int P, int mid, int G,
+                      float p, uint64_t seed, vqa_stream_t stream) {
+  VQA_REQUIRE(xs && wx && bx && score && mid % 4 == 0, "vqa_att_score_fwd: bad args");
+  const int64_t M = (int64_t)B * P;
+  DISPATCH_G(G, hipLaunchKernelGGL(att_score_fwd_kernel<kG>, dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx, bx,
+                                   score, M, P, mid, p, KEEP(p), seed));
+  return check_hip(hipGetLastError(), "att_score_fwd launch");
+}
+
+int vqa_att_row_splits(int P) {
+  int rs = (P + 127) / 128;
+  return rs < 1 ? 1 : (rs > 8 ? 8 : rs);
+}
+
+int vqa_att_score_bwd(const float* dscore, const float* wx, float* xs_inout, float* dwx_part, float* dq_part, int B,
+                      int P, int mid, int G, float p, uint64_t seed, vqa_stream_t stream) {
+  VQA_REQUIRE(dscore && wx && xs_inout && dwx_part && dq_part && mid % 4 == 0, "vqa_att_score_bwd: bad args");
+  const int RS = vqa_att_row_splits(P);
+  DISPATCH_G(G, hipLaunchKernelGGL(att_score_bwd_kernel<kG>, dim3(B, RS), dim3(256), 0, STREAM, dscore, wx, xs_inout,
+                                   dwx_part, dq_part, P, mid, RS, p, KEEP(p), seed));
+  return check_hip(hipGetLastError(), "att_score_bwd launch");
+}
+
+int vqa_att_apply_fwd(const float* score, const float* vn, float* probs, float* out, int64_t out_ld, int B, int P,
+                      int C, int G, vqa_stream_t stream) {
+  VQA_REQUIRE(score && vn && probs && out, "vqa_att_apply_fwd: null pointer");
+  const size_t lds = ((size_t)G * P + 16 + 4 * G * 64) * 4;
+  VQA_REQUIRE(lds <= 64 * 1024, "vqa_att_apply_fwd: G*P=%d too large for LDS", G * P);
+  DISPATCH_G(G, hipLaunchKernelGGL(att_apply_fwd_kernel<kG>, dim3(B, (C + 63) / 64), dim3(256), lds, STREAM, score, vn,
+                                   probs, out, out_ld, P, C));
+  return check_hip(hipGetLastError(), "att_apply_fwd launch");
+}
+
+int vqa_att_apply_bwd(const float* dout, int64_t dout_ld, const float* probs, const float* vn, float* dscore,
+                      float* dvn, int B, int P, int C, int G, vqa_stream_t stream) {
+  VQA_REQUIRE(dout && probs && vn && dscore && dvn && C % 4 == 0 && dout_ld % 4 == 0, "vqa_att_apply_bwd: bad args");
+  const int64_t M = (int64_t)B * P;
+  DISPATCH_G(G, hipLaunchKernelGGL(att_apply_bwd_rows_kernel<kG>, dim3(grid_for(M, 4)), dim3(256), 0, STREAM, dout,
+                                   dout_ld, probs, vn, dscore, dvn, M, P, C));
+  int rc = check_hip(hipGetLastError(), "att_apply_bwd_rows launch");
+  if (rc) return rc;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(B * G), dim3(256), 0, STREAM, probs, dscore, P);
+  return check_hip(hipGetLastError(), "softmax_bwd launch");
+}
+
+int vqa_softce_fwd_bwd(const float* logits, int64_t ld, const int64_t* a_idx, const int64_t* a_val, int kmax, int B,
+                       int A, float inv_batch, float* loss_rows, float* score_rows, float* dlogits, int64_t dld,
+                       vqa_stream_t stream) {
+  VQA_REQUIRE(logits && a_idx && a_val && loss_rows && score_rows && B > 0 && A > 0 && kmax >= 0,
+              "vqa_softce_fwd_bwd: bad args");
+  hipLaunchKernelGGL(softce_kernel, dim3(B), dim3(256), 0, STREAM, logits, ld, a_idx, a_val, kmax, A, inv_batch,
+                     loss_rows, score_rows, dlogits, dld);
+  return check_hip(hipGetLastError(), "softce launch");
+}
+
+int64_t vqa_colsum_workspace_bytes(int64_t rows, int cols) { return colsum_ws_bytes(rows, cols); }
+
+int vqa_colsum(const float* x, int64_t ld, const uint8_t* mask, int64_t rows, int cols, float* out, int accumulate,
+               float* workspace, int64_t workspace_bytes, vqa_stream_t stream) {
+  VQA_REQUIRE(x && out && rows > 0 && cols > 0, "vqa_colsum: bad args");
+  VQA_REQUIRE(!mask || ld == cols, "vqa_colsum: masked form needs ld == cols");
+  return colsum_launch(x, ld, mask, rows, cols, out, accumulate, workspace, workspace_bytes, STREAM);
+}
+
+int vqa_sum_bgp(const float* x, float* out, int B, int G, int P, vqa_stream_t stream) {
+  VQA_REQUIRE(x && out, "vqa_sum_bgp: null pointer");
+  hipLaunchKernelGGL(sum_bgp_kernel, dim3(G), dim3(256), 0, STREAM, x, out, B, G, P);
+  return check_hip(hipGetLastError(), "sum_bgp launch");
+}
+
+int vqa_sum_parts(const float* part, float* out, int batch, int parts, int cols, vqa_stream_t stream) {
+  VQA_REQUIRE(part && out && batch > 0 && parts > 0 && cols > 0, "vqa_sum_parts: bad args");
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((cols + 255) / 256, batch), dim3(256), 0, STREAM, part, out, parts, cols);
+  return check_hip(hipGetLastError(), "sum_parts launch");
+}
+
+int vqa_relu_drop_bwd(const float* y, const float* dy, float* dx, int64_t n, float p, uint64_t seed,
+                      vqa_stream_t stream) {
+  VQA_REQUIRE(y && dy && dx, "vqa_relu_drop_bwd: null pointer");
+  hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, y, dy, dx, n, p, KEEP(p), seed);
+  return check_hip(hipGetLastError(), "relu_drop_bwd launch");
+}
+
+int vqa_add(const float* a, const float* b, float* y, int64_t n, vqa_stream_t stream) {
+  VQA_REQUIRE(a && b && y, "vqa_add: null pointer");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, a, b, y, n);
+  return check_hip(hipGetLastError(), "add launch");
+}
+
+int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+             float beta2, float eps, int step, float grad_scale, vqa_stream_t stream) {
+  VQA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "vqa_adam: bad args");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq, n,
+                     step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+  return check_hip(hipGetLastError(), "adam launch");
+}
+
+}  // extern "C"

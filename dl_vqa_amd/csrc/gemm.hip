@@ -1,0 +1,259 @@
+// Generic fp32 MFMA GEMM (vqa_gemm) + library-wide host plumbing (errors, profiling hook).
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "gemm_core.hpp"
+
+namespace vqa {
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return VQA_OK;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return VQA_ERR_HIP;
+}
+
+// ------------------------------------------------------------------ profiling hook
+static std::mutex g_prof_mu;
+static int g_prof_id = -1, g_prof_tag = -1;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
+static thread_local int g_launch_tag = -1;
+void set_launch_tag(int tag) { g_launch_tag = tag; }
+
+ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(false) {
+  if (g_prof_id < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_id != id || (g_prof_tag >= 0 && g_prof_tag != g_launch_tag)) return;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  hipEventRecord(a, s);
+  g_prof_ev.emplace_back(a, b);
+  on = true;
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEventRecord(g_prof_ev.back().second, s);
+}
+
+// ------------------------------------------------------------------ epilogue
+struct EpiParams {
+  float* C; int64_t ldc; int M, N;
+  const float* bias1; const float* bias2;
+  const float* rg; int64_t rg_ld; int rg_div; int rg_op;
+  int relu; int accumulate;
+  float* slab;  // != nullptr: split-K partials [split][M][N]
+};
+
+__device__ __forceinline__ float epi_apply(const EpiParams& e, float v, int row, int col) {
+  if (e.rg) {
+    const float g = e.rg[(int64_t)(row / e.rg_div) * e.rg_ld + col];
+    v = e.rg_op ? v * g : v + g;
+  }
+  if (e.bias1) v += e.bias1[col];
+  if (e.bias2) v += e.bias2[col];
+  if (e.relu) v = fmaxf(v, 0.f);
+  if (e.accumulate) v += e.C[(int64_t)row * e.ldc + col];
+  return v;
+}
+
+template <class Cfg, class AL, class BL>
+__global__ __launch_bounds__(256) void gemm_kernel(typename AL::Params pa, typename BL::Params pb,
+                                                   EpiParams pe, int tiles_n, int nk, int ks_per_split,
+                                                   int Ktot) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const TileCoord tc = tile_coord(tiles_n);
+  const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
+  const int split = blockIdx.y;
+  AL al; al.init(pa, m0, tid);
+  BL bl; bl.init(pb, n0, tid);
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  acc_zero<Cfg>(acc);
+  const int ks0 = split * ks_per_split;
+  const int ks1 = min(nk, ks0 + ks_per_split);
+  gemm_mainloop<Cfg>(al, bl, acc, ks0, ks1, Ktot, smem);
+
+  float* slab = pe.slab ? pe.slab + (int64_t)split * pe.M * pe.N : nullptr;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + acc_col<Cfg>(wn, j, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
+        if (row < pe.M && col < pe.N) {
+          if (slab) slab[(int64_t)row * pe.N + col] = acc[i][j][r];
+          else pe.C[(int64_t)row * pe.ldc + col] = epi_apply(pe, acc[i][j][r], row, col);
+        }
+      }
+    }
+}
+
+__global__ void splitk_reduce_kernel(EpiParams pe, int splits) {
+  const int64_t total = (int64_t)pe.M * pe.N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += pe.slab[(int64_t)s * total + e];
+    const int row = (int)(e / pe.N), col = (int)(e - (int64_t)row * pe.N);
+    pe.C[(int64_t)row * pe.ldc + col] = epi_apply(pe, v, row, col);
+  }
+}
+
+// ------------------------------------------------------------------ host side
+struct GemmPlan { int big; int tiles_m, tiles_n, nk, splits, ks_per_split; };
+
+static GemmPlan plan_gemm(int M, int N, int K) {
+  GemmPlan p;
+  const int nk = (K + BK - 1) / BK;
+  const int t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const int t64 = ((M + 63) / 64) * ((N + 63) / 64);
+  int splits = 1;
+  if (t128 >= 200) p.big = 1;
+  else if (t64 >= 200) p.big = 0;
+  else {
+    p.big = (M >= 128 && N >= 128) ? 1 : 0;
+    const int tiles = p.big ? t128 : t64;
+    const int max_splits = nk / 4 > 1 ? nk / 4 : 1;
+    splits = (384 + tiles - 1) / tiles;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 64) splits = 64;
+  }
+  const int bm = p.big ? 128 : 64;
+  p.tiles_m = (M + bm - 1) / bm;
+  p.tiles_n = (N + bm - 1) / bm;
+  p.nk = nk;
+  p.ks_per_split = (nk + splits - 1) / splits;
+  p.splits = (nk + p.ks_per_split - 1) / p.ks_per_split;
+  return p;
+}
+
+template <class Cfg, class AL, class BL>
+static int launch_gemm(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
+                       const GemmPlan& p, int K, hipStream_t s) {
+  static bool attr_done = false;
+  auto kern = gemm_kernel<Cfg, AL, BL>;
+  if (!attr_done) {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES),
+                       "hipFuncSetAttribute(gemm)");
+    if (rc) return rc;
+    attr_done = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::SMEM_BYTES, s, pa, pb, pe, p.tiles_n, p.nk,
+                     p.ks_per_split, K);
+  return check_hip(hipGetLastError(), "gemm_kernel launch");
+}
+
+using Cfg128 = TileCfg<128, 128, 2, 2>;
+using Cfg64 = TileCfg<64, 64, 2, 2>;
+
+template <class Cfg>
+static int dispatch_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
+                         const EpiParams& pe, const GemmPlan& p, int M, int N, int K, hipStream_t s) {
+  using AR = PlainR<Cfg::NVA>; using AC = PlainC<Cfg::NVA>;
+  using BR = PlainR<Cfg::NVB>; using BC = PlainC<Cfg::NVB>;
+  if (!transA && transB) return launch_gemm<Cfg, AR, BR>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
+  if (!transA && !transB) return launch_gemm<Cfg, AR, BC>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
+  if (transA && transB) return launch_gemm<Cfg, AC, BR>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
+  return launch_gemm<Cfg, AC, BC>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
+}
+
+}  // namespace vqa
+
+using namespace vqa;
+
+extern "C" {
+
+int vqa_abi_version(void) { return VQA_ABI_VERSION; }
+const char* vqa_last_error(void) { return g_err; }
+
+int vqa_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int vqa_prof_arm(int kernel_id, int tag) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& e : g_prof_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  g_prof_ev.clear();
+  g_prof_id = kernel_id;
+  g_prof_tag = tag;
+  return VQA_OK;
+}
+
+int vqa_prof_read(int* launches, float* total_ms) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  float tot = 0.f;
+  int n = 0;
+  for (auto& e : g_prof_ev) {
+    if (hipEventSynchronize(e.second) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++n; }
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = tot;
+  return VQA_OK;
+}
+
+int64_t vqa_gemm_workspace_bytes(int M, int N, int K) {
+  const GemmPlan p = plan_gemm(M, N, K);
+  return p.splits > 1 ? (int64_t)p.splits * M * N * 4 : 0;
+}
+
+int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+             int64_t ldc, int M, int N, int K, const float* bias1, const float* bias2,
+             const float* rowgroup, int64_t rg_ld, int rg_div, int rg_op, int relu, int accumulate,
+             float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream) {
+  VQA_REQUIRE(A && B && C, "vqa_gemm: null operand");
+  VQA_REQUIRE(M > 0 && N > 0 && K > 0, "vqa_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  VQA_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && lda % 4 == 0 && ldb % 4 == 0,
+              "vqa_gemm: A/B must be 16-byte aligned with leading dimensions multiple of 4 (lda=%lld ldb=%lld)",
+              (long long)lda, (long long)ldb);
+  VQA_REQUIRE(!rowgroup || rg_div > 0, "vqa_gemm: rg_div must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const GemmPlan p = plan_gemm(M, N, K);
+  EpiParams pe{C, ldc, M, N, bias1, bias2, rowgroup, rg_ld, rg_div, rg_op, relu, accumulate, nullptr};
+  if (p.splits > 1) {
+    const int64_t need = (int64_t)p.splits * M * N * 4;
+    if (!workspace || workspace_bytes < need) {
+      set_error("vqa_gemm: workspace %lld bytes < %lld needed", (long long)workspace_bytes, (long long)need);
+      return VQA_ERR_WORKSPACE;
+    }
+    pe.slab = workspace;
+  }
+  set_launch_tag(tag);
+  int rc;
+  {
+    ProfScope prof(VQA_K_GEMM, s);
+    rc = p.big ? dispatch_gemm<Cfg128>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s)
+               : dispatch_gemm<Cfg64>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s);
+    if (rc) return rc;
+    if (p.splits > 1) {
+      const int64_t total = (int64_t)M * N;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, pe, p.splits);
+      rc = check_hip(hipGetLastError(), "splitk_reduce launch");
+    }
+  }
+  return rc;
+}
+
+}  // extern "C"

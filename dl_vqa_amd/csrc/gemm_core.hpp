@@ -1,0 +1,216 @@
+// fp32 MFMA GEMM engine for gfx950 (CDNA4), shared by every contraction on the VQA hot path.
+//
+//   C[M,N] = sum_k A(m,k) * B(k,n)       exact fp32 (v_mfma_f32_32x32x2_f32)
+//
+// Design (see DESIGN.md "GEMM engine"):
+//   * 256-thread workgroup = 4 wave64; each wave owns a (WM x WN) sub-tile made of 32x32 MFMA
+//     tiles; accumulators stay in registers for the whole K loop.
+//   * Operands are staged through LDS in K-major images  As[BK][BM+1], Bs[BK][BN+1]:
+//     an MFMA A/B fragment is ONE dword per lane (lane l: row l&31, k = 2s + (l>>5)), so a
+//     fragment read is a stride-1 ds_read_b32 across 32 lanes: conflict free by construction.
+//   * Two kinds of operand loader fill those images from global memory, both with 16-byte
+//     per-lane loads, 8 lanes covering one 128-byte line:
+//       type R ("k-contiguous rows"):  thread -> (row r, k-chunk c); transposing LDS write
+//       type C ("reduction-major"):    thread -> (k-row kr, m-chunk c); straight LDS write
+//     Row addresses come from a functor, which is how implicit-im2col (conv forward), the
+//     max-pool-routed gradient (conv dgrad / wgrad) and plain matrices share one main loop.
+//   * Register-staged double buffering: the global loads of K-step s+1 are issued before the
+//     MFMAs of step s and written to the other LDS buffer after them; one barrier per K-step.
+//     fp32 MFMA is 64 cycles per instruction per SIMD, so one K-step (BK = 32) is >= 1024
+//     MFMA cycles per wave, which covers an HBM round trip.
+#pragma once
+#include "common.hpp"
+
+namespace vqa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;  // K-step depth (floats): 8 lanes x 16 B = one 128-B line per row
+
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
+struct TileCfg {
+  static_assert(WAVES_M_ * WAVES_N_ == 4, "4 waves per workgroup");
+  static constexpr int BM = BM_, BN = BN_;
+  static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile = 32x32 MFMA tiles");
+  static constexpr int LDA = BM + 1, LDB = BN + 1;  // == 1 (mod 32): conflict-free transposing writes
+  static constexpr int NVA = BM / 32, NVB = BN / 32;  // float4 per thread per K-step
+  static constexpr int SMEM_FLOATS = 2 * BK * (LDA + LDB);
+  static constexpr int SMEM_BYTES = SMEM_FLOATS * 4;
+};
+
+// Thread -> staging coordinates, common to both loader types.
+//   r32 = tid >> 3 (0..31), c8 = tid & 7 (0..7)
+// type R: rows r32 + 32*p (p < BM/32), k-chunk c8 (k = 4*c8 .. 4*c8+3)
+// type C: k-row r32, m-chunks c8 + 8*p (m = 4*(c8+8p) .. +3)
+template <int LD, int NV>
+__device__ __forceinline__ void lds_store_R(float* s, const float4 (&r)[NV], int tid) {
+  const int r32 = tid >> 3, c8 = tid & 7;
+#pragma unroll
+  for (int p = 0; p < NV; ++p) {
+    float* d = s + (4 * c8) * LD + r32 + 32 * p;
+    d[0] = r[p].x; d[LD] = r[p].y; d[2 * LD] = r[p].z; d[3 * LD] = r[p].w;
+  }
+}
+template <int LD, int NV>
+__device__ __forceinline__ void lds_store_C(float* s, const float4 (&r)[NV], int tid) {
+  const int r32 = tid >> 3, c8 = tid & 7;
+#pragma unroll
+  for (int p = 0; p < NV; ++p) {
+    float* d = s + r32 * LD + 4 * (c8 + 8 * p);
+    d[0] = r[p].x; d[1] = r[p].y; d[2] = r[p].z; d[3] = r[p].w;
+  }
+}
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Guarded 16-byte load of elements [k, k+4) of a row that holds `kmax` valid elements.
+__device__ __forceinline__ float4 load4_guard(const float* p, int k, int kmax) {
+  if (k + 3 < kmax) return *reinterpret_cast<const float4*>(p + k);
+  float4 v = f4zero();
+  if (k < kmax) v.x = p[k];
+  if (k + 1 < kmax) v.y = p[k + 1];
+  if (k + 2 < kmax) v.z = p[k + 2];
+  return v;
+}
+
+// ---------------------------------------------------------------- plain matrix loaders
+// Type R over a row-major matrix X[rows][K] (ld floats per row): used for A=[M][K] and B=[N][K].
+template <int NV>
+struct PlainR {
+  struct Params { const float* p; int64_t ld; int rows; int K; };
+  static constexpr bool kTypeR = true;
+  const float* rowp[NV];
+  bool ok[NV];
+  int K, c4;
+  __device__ __forceinline__ void init(const Params& q, int row0, int tid) {
+    K = q.K; c4 = 4 * (tid & 7);
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int r = row0 + (tid >> 3) + 32 * p;
+      ok[p] = r < q.rows;
+      rowp[p] = q.p + (int64_t)(ok[p] ? r : 0) * q.ld;
+    }
+  }
+  __device__ __forceinline__ void load(int ks, float4 (&r)[NV]) const {
+    const int k = ks * BK + c4;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) r[p] = ok[p] ? load4_guard(rowp[p], k, K) : f4zero();
+  }
+};
+
+// Type C over a row-major matrix X[K][cols] (reduction index is the slow one).
+template <int NV>
+struct PlainC {
+  struct Params { const float* p; int64_t ld; int cols; int K; };
+  static constexpr bool kTypeR = false;
+  const float* base;
+  int64_t ld;
+  int K, cols, col0, kr;
+  __device__ __forceinline__ void init(const Params& q, int col0_, int tid) {
+    base = q.p; ld = q.ld; K = q.K; cols = q.cols; col0 = col0_ + 4 * (tid & 7); kr = tid >> 3;
+  }
+  __device__ __forceinline__ void load(int ks, float4 (&r)[NV]) const {
+    const int k = ks * BK + kr;
+    const float* row = base + (int64_t)k * ld;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) r[p] = (k < K) ? load4_guard(row, col0 + 32 * p, cols) : f4zero();
+  }
+};
+
+// ---------------------------------------------------------------- the main loop
+template <class Cfg>
+__device__ __forceinline__ void mma_kstep(const float* As, const float* Bs,
+                                          f32x16 (&acc)[Cfg::TM][Cfg::TN], int wm, int wn, int lane,
+                                          int kvalid) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const float* ap = As + h * Cfg::LDA + wm * Cfg::WM + l31;
+  const float* bp = Bs + h * Cfg::LDB + wn * Cfg::WN + l31;
+#pragma unroll
+  for (int g = 0; g < BK / 8; ++g) {
+    if (g * 8 < kvalid) {  // block-uniform: skips all-zero tails of the last K-step
+#pragma unroll
+      for (int s = g * 4; s < g * 4 + 4; ++s) {
+        float a[Cfg::TM], b[Cfg::TN];
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) a[i] = ap[2 * s * Cfg::LDA + 32 * i];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) b[j] = bp[2 * s * Cfg::LDB + 32 * j];
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < Cfg::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <class Cfg, class AL, class BL>
+__device__ __forceinline__ void gemm_mainloop(const AL& al, const BL& bl,
+                                              f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
+                                              int Ktot, float* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  float* const As0 = smem;
+  float* const Bs0 = smem + 2 * BK * Cfg::LDA;
+  float4 ra[Cfg::NVA], rb[Cfg::NVB];
+  if (ks0 >= ks1) return;
+  al.load(ks0, ra);
+  bl.load(ks0, rb);
+  if (AL::kTypeR) lds_store_R<Cfg::LDA, Cfg::NVA>(As0, ra, tid); else lds_store_C<Cfg::LDA, Cfg::NVA>(As0, ra, tid);
+  if (BL::kTypeR) lds_store_R<Cfg::LDB, Cfg::NVB>(Bs0, rb, tid); else lds_store_C<Cfg::LDB, Cfg::NVB>(Bs0, rb, tid);
+  __syncthreads();
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int cur = (ks - ks0) & 1;
+    const bool more = ks + 1 < ks1;
+    if (more) { al.load(ks + 1, ra); bl.load(ks + 1, rb); }
+    int kvalid = Ktot - ks * BK;
+    kvalid = kvalid > BK ? BK : kvalid;
+    float* const Ac = As0 + cur * (BK * Cfg::LDA);
+    float* const Bc = Bs0 + cur * (BK * Cfg::LDB);
+    float* const An = As0 + (cur ^ 1) * (BK * Cfg::LDA);
+    float* const Bn = Bs0 + (cur ^ 1) * (BK * Cfg::LDB);
+    mma_kstep<Cfg>(Ac, Bc, acc, wm, wn, lane, kvalid);
+    if (more) {
+      if (AL::kTypeR) lds_store_R<Cfg::LDA, Cfg::NVA>(An, ra, tid); else lds_store_C<Cfg::LDA, Cfg::NVA>(An, ra, tid);
+      if (BL::kTypeR) lds_store_R<Cfg::LDB, Cfg::NVB>(Bn, rb, tid); else lds_store_C<Cfg::LDB, Cfg::NVB>(Bn, rb, tid);
+    }
+    __syncthreads();
+  }
+}
+
+template <class Cfg>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// Accumulator element (i, j, r) of this lane is C[row][col] with
+//   row = wm*WM + 32*i + (r&3) + 8*(r>>2) + 4*(lane>>5),  col = wn*WN + 32*j + (lane&31)
+// (C/D map of v_mfma_f32_32x32x2_f32; rows come from the A operand, columns from B).
+template <class Cfg>
+__device__ __forceinline__ int acc_row(int wm, int i, int r, int lane) {
+  return wm * Cfg::WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+template <class Cfg>
+__device__ __forceinline__ int acc_col(int wn, int j, int lane) {
+  return wn * Cfg::WN + 32 * j + (lane & 31);
+}
+
+// Tile id -> (mt, nt, split).  nt runs fastest so workgroups that share an A panel are neighbours,
+// and xcd_swizzle keeps neighbours on one XCD (shared L2).
+struct TileCoord { int mt, nt; };
+__device__ __forceinline__ TileCoord tile_coord(int tiles_n) {
+  const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+  TileCoord c; c.mt = t / tiles_n; c.nt = t - c.mt * tiles_n;
+  return c;
+}
+
+}  // namespace vqa

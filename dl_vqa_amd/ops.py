@@ -1,0 +1,223 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/vqa_hip.h).
+
+torch supplies device memory and the current HIP stream; every computation happens in the HIP
+library.  Nothing here falls back to torch arithmetic.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+_ws = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """A per-device scratch buffer that only grows (split-K slabs, reduction partials)."""
+    key = str(device)
+    t = _ws.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty(max(nbytes // 4 + 1024, 1 << 20), dtype=torch.float32, device=device)
+        _ws[key] = t
+    return t
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype, (t.device, t.dtype)
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, *, transA=False,
+         transB=True, lda=None, ldb=None, ldc=None, bias1=None, bias2=None, rowgroup=None, rg_div=1,
+         rg_op=0, relu=False, accumulate=False, tag=0) -> torch.Tensor:
+    """C[M,N] = act(op(A) op(B) (op) rowgroup + bias) (+C).  Leading dims default to the stored row length."""
+    lib = _lib.load()
+    lda = lda if lda is not None else (M if transA else K)
+    ldb = ldb if ldb is not None else (K if transB else N)
+    ldc = ldc if ldc is not None else N
+    nbytes = lib.vqa_gemm_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, A.device) if nbytes else None
+    call("vqa_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(C), ldc, M, N, K,
+         ptr(bias1), ptr(bias2), ptr(rowgroup), (rowgroup.stride(0) if rowgroup is not None else 0),
+         rg_div, rg_op, int(relu), int(accumulate), ptr(ws), (ws.numel() * 4 if ws is not None else 0),
+         tag, stream())
+    return C
+
+
+def nchw_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
+    B, Cc, H, W = x.shape
+    y = torch.empty(B, H, W, 4, dtype=torch.float32, device=x.device)
+    call("vqa_nchw_to_nhwc4", ptr(x), ptr(y), B, Cc, H, W, stream())
+    return y
+
+
+def conv_pack_weights(w: torch.Tensor, CiP: int, need_wd: bool = True):
+    Co, Ci = w.shape[0], w.shape[1]
+    wf = torch.empty(9 * CiP, Co, dtype=torch.float32, device=w.device)
+    wd = torch.empty(9 * Co, CiP, dtype=torch.float32, device=w.device) if need_wd else None
+    call("vqa_conv_pack_weights", ptr(w), ptr(wf), ptr(wd), Co, Ci, CiP, stream())
+    return wf, wd
+
+
+def conv_out_hw(H: int, W: int, stride: int) -> Tuple[int, int]:
+    return ((H - 3) // stride + 1) // 2, ((W - 3) // stride + 1) // 2
+
+
+def conv_fwd(x: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor, stride: int = 1, tag: int = 0):
+    """x NHWC [B,H,W,CiP] -> (pooled [B,Hp,Wp,Co], argmax uint8 same shape)."""
+    B, H, W, CiP = x.shape
+    Co = wf.shape[1]
+    Hp, Wp = conv_out_hw(H, W, stride)
+    pooled = torch.empty(B, Hp, Wp, Co, dtype=torch.float32, device=x.device)
+    amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x.device)
+    call("vqa_conv3x3_relu_pool_fwd", ptr(x), ptr(wf), ptr(bias), ptr(pooled), ptr(amax), B, H, W, CiP, Co,
+         stride, tag, stream())
+    return pooled, amax
+
+
+def conv_dgrad(dpooled, amax, wd, x_shape, stride: int = 1, tag: int = 0, out=None) -> torch.Tensor:
+    B, H, W, CiP = x_shape
+    Co = dpooled.shape[3]
+    dx = out if out is not None else torch.empty(B, H, W, CiP, dtype=torch.float32, device=dpooled.device)
+    call("vqa_conv3x3_dgrad", ptr(dpooled), ptr(amax), ptr(wd), ptr(dx), B, H, W, CiP, Co, stride, tag, stream())
+    return dx
+
+
+def conv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: int = 1, tag: int = 0):
+    lib = _lib.load()
+    B, H, W, CiP = x.shape
+    Co, Ci = dw.shape[0], dw.shape[1]
+    nbytes = lib.vqa_conv3x3_wgrad_workspace_bytes(B, H, W, CiP, Co, stride)
+    ws = workspace(nbytes, x.device)
+    call("vqa_conv3x3_wgrad", ptr(x), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co, stride,
+         ptr(ws), ws.numel() * 4, tag, stream())
+
+
+def dropout(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    y = out if out is not None else torch.empty_like(x)
+    call("vqa_dropout", ptr(x), ptr(y), x.numel(), p, seed, stream())
+    return y
+
+
+def l2norm_fwd(pooled: torch.Tensor, p: float, seed: int):
+    C = pooled.shape[-1]
+    rows = pooled.numel() // C
+    vn = torch.empty_like(pooled)
+    norm = torch.empty(rows, dtype=torch.float32, device=pooled.device)
+    call("vqa_l2norm_fwd", ptr(pooled), ptr(vn), ptr(norm), rows, C, p, seed, stream())
+    return vn, norm
+
+
+def l2norm_bwd(dvn, vn, norm, p: float, seed: int, out=None):
+    C = vn.shape[-1]
+    d = out if out is not None else torch.empty_like(vn)
+    call("vqa_l2norm_bwd", ptr(dvn), ptr(vn), ptr(norm), ptr(d), vn.numel() // C, C, p, seed, stream())
+    return d
+
+
+def embed_tanh_fwd(q: torch.Tensor, emb: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    B, T = q.shape
+    V, E = emb.shape
+    x = torch.empty(T, B, E, dtype=torch.float32, device=emb.device)
+    call("vqa_embed_tanh_fwd", ptr(q), ptr(emb), ptr(x), B, T, E, V, p, seed, stream())
+    return x
+
+
+def embed_tanh_bwd(q, x, dx, demb, p: float, seed: int):
+    B, T = q.shape
+    V, E = demb.shape
+    call("vqa_embed_tanh_bwd", ptr(q), ptr(x), ptr(dx), ptr(demb), B, T, E, V, p, seed, stream())
+
+
+def lstm_cell_fwd(xg_t, hg, c_in, h_in, q_len, t, gates, c_out, h_out, c_final=None, cf_ld=0):
+    B, H = c_in.shape
+    call("vqa_lstm_cell_fwd", ptr(xg_t), ptr(hg), ptr(c_in), ptr(h_in), ptr(q_len), t, ptr(gates), ptr(c_out),
+         ptr(h_out), ptr(c_final), cf_ld, B, H, stream())
+
+
+def lstm_cell_bwd(gates, c_in, c_out, q_len, t, dh, dc, dgates):
+    B, H = c_in.shape
+    call("vqa_lstm_cell_bwd", ptr(gates), ptr(c_in), ptr(c_out), ptr(q_len), t, ptr(dh), ptr(dc), ptr(dgates),
+         B, H, stream())
+
+
+def att_score_fwd(xs, wx, bx, B, P, p: float, seed: int) -> torch.Tensor:
+    G, mid = wx.shape[0], wx.shape[1]
+    score = torch.empty(B, G, P, dtype=torch.float32, device=xs.device)
+    call("vqa_att_score_fwd", ptr(xs), ptr(wx), ptr(bx), ptr(score), B, P, mid, G, p, seed, stream())
+    return score
+
+
+def att_score_bwd(dscore, wx, xs_inout, B, P, p: float, seed: int):
+    lib = _lib.load()
+    G, mid = wx.shape[0], wx.shape[1]
+    RS = lib.vqa_att_row_splits(P)
+    dwx_part = torch.empty(B * RS, G * mid, dtype=torch.float32, device=wx.device)
+    dq_part = torch.empty(B * RS, mid, dtype=torch.float32, device=wx.device)
+    call("vqa_att_score_bwd", ptr(dscore), ptr(wx), ptr(xs_inout), ptr(dwx_part), ptr(dq_part), B, P, mid, G, p,
+         seed, stream())
+    return dwx_part, dq_part, RS
+
+
+def att_apply_fwd(score, vn, out, out_ld):
+    B, G, P = score.shape
+    C = vn.shape[-1]
+    probs = torch.empty_like(score)
+    call("vqa_att_apply_fwd", ptr(score), ptr(vn), ptr(probs), ptr(out), out_ld, B, P, C, G, stream())
+    return probs
+
+
+def att_apply_bwd(dout, dout_ld, probs, vn, dvn_out=None):
+    B, G, P = probs.shape
+    C = vn.shape[-1]
+    dscore = torch.empty_like(probs)
+    dvn = dvn_out if dvn_out is not None else torch.empty_like(vn)
+    call("vqa_att_apply_bwd", ptr(dout), dout_ld, ptr(probs), ptr(vn), ptr(dscore), ptr(dvn), B, P, C, G, stream())
+    return dscore, dvn
+
+
+def softce(logits, ld, a_idx, a_val, A, inv_batch, dlogits=None, dld=0):
+    B = logits.shape[0]
+    kmax = a_idx.shape[1]
+    loss_rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+    score_rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+    call("vqa_softce_fwd_bwd", ptr(logits), ld, ptr(a_idx), ptr(a_val), kmax, B, A, inv_batch, ptr(loss_rows),
+         ptr(score_rows), ptr(dlogits), dld, stream())
+    return loss_rows, score_rows
+
+
+def colsum(x: torch.Tensor, rows: int, cols: int, out: torch.Tensor, *, ld=None, mask=None, accumulate=False):
+    lib = _lib.load()
+    nbytes = lib.vqa_colsum_workspace_bytes(rows, cols)
+    ws = workspace(nbytes, x.device)
+    call("vqa_colsum", ptr(x), ld if ld is not None else cols, ptr(mask), rows, cols, ptr(out), int(accumulate),
+         ptr(ws), ws.numel() * 4, stream())
+    return out
+
+
+def sum_bgp(x: torch.Tensor, out: torch.Tensor):
+    B, G, P = x.shape
+    call("vqa_sum_bgp", ptr(x), ptr(out), B, G, P, stream())
+    return out
+
+
+def sum_parts(part: torch.Tensor, out: torch.Tensor, batch: int, parts: int, cols: int):
+    call("vqa_sum_parts", ptr(part), ptr(out), batch, parts, cols, stream())
+    return out
+
+
+def relu_drop_bwd(y, dy, dx, p: float, seed: int):
+    call("vqa_relu_drop_bwd", ptr(y), ptr(dy), ptr(dx), y.numel(), p, seed, stream())
+    return dx
+
+
+def add(a, b, out):
+    call("vqa_add", ptr(a), ptr(b), ptr(out), a.numel(), stream())
+    return out
+
+
+def adam(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    call("vqa_adam", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
+         step, grad_scale, stream())

@@ -1,0 +1,175 @@
+/* vqa_hip.h — C ABI of libvqa_hip.so: the MI355X (gfx950) kernels behind VqaNet.forward/backward.
+ *
+ * The reference (OmerShubi/DL_VQA) has no FFI layer: its hot path is a chain of stock torch
+ * operators inside models/model.py:53-67 and train.py:189-206.  Each entry point below replaces
+ * one fused stage of that chain; the reference lines it stands in for are cited per function.
+ *
+ * Conventions:
+ *   - every tensor argument is a raw DEVICE pointer into caller-owned memory (torch storage);
+ *     the library never allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
+ *   - return value: 0 = success, otherwise a VQA_ERR_* code; vqa_last_error() gives the text;
+ *   - no C++ exception crosses the ABI; functions are stateless and re-entrant apart from the
+ *     optional profiling hook;
+ *   - all floating point is IEEE fp32; contractions use v_mfma_f32_32x32x2_f32 (exact fp32);
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS; pointers and leading
+ *     dimensions of GEMM operands must be multiples of 4 elements (16-byte vector loads);
+ *   - images inside the library are NHWC; question activations are time-major [T][B][*].
+ */
+#ifndef VQA_HIP_H
+#define VQA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQA_ABI_VERSION 1
+
+#define VQA_OK 0
+#define VQA_ERR_INVALID 1 /* bad argument (shape, alignment, null pointer) */
+#define VQA_ERR_HIP 2     /* a HIP runtime call or kernel launch failed */
+#define VQA_ERR_WORKSPACE 3 /* workspace too small */
+
+typedef void* vqa_stream_t; /* hipStream_t */
+
+int vqa_abi_version(void);
+const char* vqa_last_error(void);
+/* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never fails). */
+int vqa_device_ok(void);
+
+/* ---- profiling hook (bench.py: live HIP-event timing of one kernel family) ------------------ */
+enum {
+  VQA_K_GEMM = 0,
+  VQA_K_CONV_FWD = 1,
+  VQA_K_CONV_DGRAD = 2,
+  VQA_K_CONV_WGRAD = 3,
+  VQA_K_COUNT = 4
+};
+/* Arm event bracketing for kernel family `kernel_id` whose launch tag equals `tag`
+ * (tag < 0: any). kernel_id < 0 disarms. Resets the accumulated numbers. */
+int vqa_prof_arm(int kernel_id, int tag);
+/* Synchronise the recorded events; returns launches counted and their total device time. */
+int vqa_prof_read(int* launches, float* total_ms);
+
+/* ---- generic GEMM ---------------------------------------------------------------------------
+ * C[M][N] = act( A.B  (op) rowgroup + bias1 + bias2 ) (+ C if accumulate)
+ *   transA = 0: A stored [M][K];  1: A stored [K][M]
+ *   transB = 0: B stored [K][N];  1: B stored [N][K]   (torch nn.Linear weight => transB = 1)
+ *   rowgroup (optional): value rowgroup[(m / rg_div) * rg_ld + n], rg_op 0 = add, 1 = multiply
+ *     (the question projection tiled over image positions, models/model.py:187-193,224-231)
+ *   relu: 0/1.   tag: free integer recorded by the profiling hook.
+ * Replaces nn.Linear / 1x1 nn.Conv2d / LSTM projections (models/model.py:145,173-174,202,205)
+ * and every dX / dW product of their backward passes.
+ * Small outputs are split along K over workgroups; partial slabs live in `workspace`. */
+int64_t vqa_gemm_workspace_bytes(int M, int N, int K);
+int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
+             float* C, int64_t ldc, int M, int N, int K, const float* bias1, const float* bias2,
+             const float* rowgroup, int64_t rg_ld, int rg_div, int rg_op, int relu, int accumulate,
+             float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
+
+/* ---- image encoder: Conv2d(k=3, stride, pad=0) + ReLU + MaxPool2d(2,2) ----------------------
+ * (models/model.py:72-84 ImageNet2). Activations NHWC, channel count padded to a multiple of 4
+ * (CiP); weights re-packed per step from the torch layout [Co][Ci][3][3]. */
+int vqa_nchw_to_nhwc4(const float* x_nchw, float* y_nhwc, int B, int C, int H, int W, vqa_stream_t stream);
+/* wf[(ky*3+kx)*CiP + ci][co], wd[(ky*3+kx)*Co + co][ci]  (wd may be NULL) */
+int vqa_conv_pack_weights(const float* w, float* wf, float* wd, int Co, int Ci, int CiP, vqa_stream_t stream);
+/* pooled[B][Hp][Wp][Co], argmax[B][Hp][Wp][Co] in {0..3 = dy*2+dx of the winning pre-activation,
+ * 4 = window dead (max <= 0, ReLU blocks the gradient)}; Hp = ((H-3)/stride+1)/2 (floor). */
+int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias, float* pooled,
+                              uint8_t* argmax, int B, int H, int W, int CiP, int Co, int stride,
+                              int tag, vqa_stream_t stream);
+/* dx[B][H][W][CiP] = gradient w.r.t. the conv input, routed through arg-max and ReLU. */
+int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* wd, float* dx, int B,
+                      int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream);
+/* dw[Co][Ci][3][3] and dbias[Co] (torch layouts; written, not accumulated). */
+int64_t vqa_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride);
+int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argmax, float* dw,
+                      float* dbias, int B, int H, int W, int CiP, int Ci, int Co, int stride,
+                      float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
+
+/* ---- dropout (nn.Dropout, 7 sites: models/model.py:84,156,185,186,194,201,204) ---------------
+ * y = x * keep(seed, i) / (1-p); keep() is a counter-based hash, so backward calls the same
+ * function on the gradient. In-place allowed. */
+int vqa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa_stream_t stream);
+
+/* ---- L2 normalisation over channels (models/model.py:56), fused with image.drop (model.py:84) -
+ * u = dropout(pooled); norm = ||u||_2 per row; vn = u / (norm + 1e-12).  rows = B*P, C channels. */
+int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p,
+                   uint64_t seed, vqa_stream_t stream);
+int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, float* dpooled, int64_t rows,
+                   int C, float p, uint64_t seed, vqa_stream_t stream);
+
+/* ---- question encoder (models/model.py:134-166 questionNet) ----------------------------------
+ * x[t][b][:] = tanh(dropout(emb[q[b][t]]))   (embedding -> drop -> tanh, model.py:155-157) */
+int vqa_embed_tanh_fwd(const int64_t* q, const float* emb, float* x, int B, int T, int E, int V,
+                       float p, uint64_t seed, vqa_stream_t stream);
+/* demb[q[b][t]] += dx * (1 - x^2) * dropmask, token 0 skipped (padding_idx=0). demb pre-zeroed. */
+int vqa_embed_tanh_bwd(const int64_t* q, const float* x, const float* dx, float* demb, int B, int T,
+                       int E, int V, float p, uint64_t seed, vqa_stream_t stream);
+/* One LSTM time step for one direction (gate order i,f,g,o; nn.LSTM, model.py:145-149):
+ *   pre = xg[b] + hg[b]   (xg = x W_ih^T + b_ih + b_hh for time t, hg = h_in W_hh^T, both [B][4H])
+ *   rows with t >= q_len[b] keep (h,c) unchanged — the packed-sequence semantics of model.py:159-164.
+ * Writes activated gates [B][4H], c_out, h_out; if c_final != NULL also c_final[b*cf_ld + j]. */
+int vqa_lstm_cell_fwd(const float* xg, const float* hg, const float* c_in, const float* h_in,
+                      const int64_t* q_len, int t, float* gates, float* c_out, float* h_out,
+                      float* c_final, int64_t cf_ld, int B, int H, vqa_stream_t stream);
+/* Backward of one step. In: dh [B][H] (grad w.r.t. h_out), dc [B][H] (grad w.r.t. c_out).
+ * Out: dgates [B][4H] (pre-activation grads, 0 for inactive rows), dc <- grad w.r.t. c_in,
+ * dh <- pass-through part of grad w.r.t. h_in (dh for inactive rows, 0 for active rows); the caller
+ * then accumulates dgates.W_hh onto dh with vqa_gemm(accumulate=1). */
+int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out, const int64_t* q_len,
+                      int t, float* dh, float* dc, float* dgates, int B, int H, vqa_stream_t stream);
+
+/* ---- attention (models/model.py:169-195 Attention, 208-221 image_question_attention) ---------
+ * xs[m][n] = relu(v'(m,n) (+|*) q'(b,n)) comes from vqa_gemm(rowgroup=q'); then
+ * score[b][g][p] = bx[g] + sum_n dropout(xs[b*P+p][n]) * wx[g][n]      (x_conv, model.py:194) */
+int vqa_att_score_fwd(const float* xs, const float* wx, const float* bx, float* score, int B, int P,
+                      int mid, int G, float p, uint64_t seed, vqa_stream_t stream);
+/* In place: xs <- dxpre = (xs > 0) * dropmask * sum_g dscore[b][g][p] wx[g][n]; and per-workgroup
+ * partial sums  dwx_part[b*RS+rs][G][mid], dq_part[b*RS+rs][mid]  (RS = vqa_att_row_splits(P)):
+ *   dwx = sum over parts of dscore * dropout(xs);  dq' (for '+') = sum over parts of dxpre. */
+int vqa_att_row_splits(int P);
+int vqa_att_score_bwd(const float* dscore, const float* wx, float* xs_inout, float* dwx_part,
+                      float* dq_part, int B, int P, int mid, int G, float p, uint64_t seed,
+                      vqa_stream_t stream);
+/* probs = softmax_p(score); out[b*out_ld + g*C + c] = sum_p probs[b][g][p] * vn[b][p][c] */
+int vqa_att_apply_fwd(const float* score, const float* vn, float* probs, float* out, int64_t out_ld,
+                      int B, int P, int C, int G, vqa_stream_t stream);
+/* dscore[b][g][p] and dvn[b][p][c] (written) from dout[b*dout_ld + g*C + c]. */
+int vqa_att_apply_bwd(const float* dout, int64_t dout_ld, const float* probs, const float* vn,
+                      float* dscore, float* dvn, int B, int P, int C, int G, vqa_stream_t stream);
+
+/* ---- loss head (train.py:190-207, utils/train_utils.py:12-25) -------------------------------
+ * loss_rows[b] = sum_k -log_softmax(logits[b])[a_idx[b][k]-1] * a_val[b][k]/10 * inv_batch
+ * score_rows[b] = min(1, 0.3 * a_val of the arg-max answer)
+ * dlogits (optional) = d(sum_b loss_rows)/dlogits. a_idx is 1-based, 0 = padding. */
+int vqa_softce_fwd_bwd(const float* logits, int64_t ld, const int64_t* a_idx, const int64_t* a_val,
+                       int kmax, int B, int A, float inv_batch, float* loss_rows, float* score_rows,
+                       float* dlogits, int64_t dld, vqa_stream_t stream);
+
+/* ---- reductions / pointwise helpers -------------------------------------------------------- */
+/* out[n] (+)= sum_m x[m*ld + n]; if mask != NULL rows of x where mask[m*cols+n] == 4 are skipped
+ * (conv bias gradient over dead pool windows). workspace: vqa_colsum_workspace_bytes(rows, cols). */
+int64_t vqa_colsum_workspace_bytes(int64_t rows, int cols);
+int vqa_colsum(const float* x, int64_t ld, const uint8_t* mask, int64_t rows, int cols, float* out,
+               int accumulate, float* workspace, int64_t workspace_bytes, vqa_stream_t stream);
+/* out[g] = sum_{b,p} x[b][g][p] */
+int vqa_sum_bgp(const float* x, float* out, int B, int G, int P, vqa_stream_t stream);
+/* out[b][n] = sum_r part[(b*parts + r)*cols + n] */
+int vqa_sum_parts(const float* part, float* out, int batch, int parts, int cols, vqa_stream_t stream);
+/* dx = dy * dropmask * (y > 0): backward of dropout(relu(.)) given y = relu output (model.py:201-204) */
+int vqa_relu_drop_bwd(const float* y, const float* dy, float* dx, int64_t n, float p, uint64_t seed,
+                      vqa_stream_t stream);
+/* y = a + b (element-wise; in-place allowed) */
+int vqa_add(const float* a, const float* b, float* y, int64_t n, vqa_stream_t stream);
+
+/* ---- optimiser: torch.optim.Adam defaults over one flat buffer (train.py:55,80) ------------- */
+int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+             float beta1, float beta2, float eps, int step, float grad_scale, vqa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_HIP_H */

@@ -1,0 +1,347 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (dl_vqa_amd.ops -> libvqa_hip.so).
+
+Each HIP entry point is compared with a float64 torch-CPU computation of the same operator
+(floating-point kernels: tolerance stated per test, relative to the magnitude of the result).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from dl_vqa_amd import ops
+    return ops
+
+
+def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    scale = max(float(ref.abs().max()), 1e-30)
+    return float((got - ref).abs().max()) / scale
+
+
+def check(name, got, ref, tol):
+    e = rel_err(got, ref)
+    print(f"[parity] {name}: max|err|/max|ref| = {e:.3e} (tol {tol:.1e})")
+    assert e <= tol, f"{name}: {e} > {tol}"
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 200, 100), (64, 64, 32), (5, 3, 8), (256, 1024, 2560),
+                                   (1030, 260, 3584), (129, 4096, 300)])
+@pytest.mark.parametrize("transA,transB", [(False, True), (False, False), (True, True), (True, False)])
+def test_gemm_layouts(M, N, K, transA, transB):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    ref = A.double() @ Bm.double()
+    pad = lambda n: (n + 3) // 4 * 4
+    if transA:   # stored [K][M]
+        As = torch.zeros(K, pad(M)); As[:, :M] = A.t(); lda = pad(M)
+    else:
+        As = torch.zeros(M, pad(K)); As[:, :K] = A; lda = pad(K)
+    if transB:   # stored [N][K]
+        Bs = torch.zeros(N, pad(K)); Bs[:, :K] = Bm.t(); ldb = pad(K)
+    else:
+        Bs = torch.zeros(K, pad(N)); Bs[:, :N] = Bm; ldb = pad(N)
+    Cd = torch.full((M, N + 3), 7.0, device=DEV)
+    ops.gemm(As.to(DEV), Bs.to(DEV), Cd, M, N, K, transA=transA, transB=transB, lda=lda, ldb=ldb, ldc=N + 3)
+    torch.cuda.synchronize()
+    check(f"gemm {M}x{N}x{K} tA={transA} tB={transB}", Cd[:, :N], ref, 2e-6 * math.sqrt(K))
+    assert float((Cd[:, N:] - 7.0).abs().max()) == 0.0   # nothing written outside N
+
+
+def test_gemm_epilogue_bias_rowgroup_relu_accumulate():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    Bn, P, K, N = 3, 7, 40, 36
+    M = Bn * P
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    b1, b2 = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    rg = torch.randn(Bn, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    acc = A.double() @ W.double().t()
+    for op in (0, 1):
+        rgx = rg.double().repeat_interleave(P, dim=0)
+        ref = acc + rgx if op == 0 else acc * rgx
+        ref = torch.relu(ref + b1.double() + b2.double()) + C0.double()
+        Cd = C0.clone().to(DEV)
+        ops.gemm(A.to(DEV), W.to(DEV), Cd, M, N, K, bias1=b1.to(DEV), bias2=b2.to(DEV), rowgroup=rg.to(DEV),
+                 rg_div=P, rg_op=op, relu=True, accumulate=True)
+        torch.cuda.synchronize()
+        check(f"gemm epilogue rg_op={op}", Cd, ref, 1e-5)
+    # split-K path with epilogue (small output, long K)
+    M, N, K = 64, 48, 4096
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    b1 = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = torch.relu(A.double() @ W.double().t() + b1.double()) + C0.double()
+    Cd = C0.clone().to(DEV)
+    ops.gemm(A.to(DEV), W.to(DEV), Cd, M, N, K, bias1=b1.to(DEV), relu=True, accumulate=True)
+    torch.cuda.synchronize()
+    check("gemm split-K epilogue", Cd, ref, 2e-5)
+
+
+def test_gemm_rejects_misaligned():
+    from dl_vqa_amd._lib import VqaHipError
+    ops = _ops()
+    A = torch.zeros(8, 10, device=DEV)
+    B = torch.zeros(8, 10, device=DEV)
+    Cd = torch.zeros(8, 8, device=DEV)
+    with pytest.raises(VqaHipError):
+        ops.gemm(A, B, Cd, 8, 8, 10)        # lda = 10 is not a multiple of 4
+
+
+# ----------------------------------------------------------------------------- conv + relu + pool
+def _nhwc(x, cpad=None):
+    x = x.permute(0, 2, 3, 1).contiguous()
+    if cpad and cpad != x.shape[-1]:
+        x = F.pad(x, (0, cpad - x.shape[-1]))
+    return x.contiguous()
+
+
+CONV_CASES = [  # B, H, W, Ci, Co, stride
+    (2, 16, 16, 8, 16, 1),
+    (3, 31, 29, 3, 8, 1),      # Ci=3 padded to 4, odd sizes (floor in conv and pool)
+    (2, 33, 35, 8, 12, 2),     # stride 2
+    (2, 58, 58, 64, 128, 1),   # the conv1 shape family (128x128 tile)
+    (1, 30, 30, 128, 256, 1),  # conv2 shape family
+    (2, 40, 40, 4, 64, 1),     # conv0 shape family (NHWC4, 128x64 tile)
+]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride", CONV_CASES)
+def test_conv_relu_pool_fwd_bwd(B, H, W, Ci, Co, stride):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Ci)
+    CiP = (Ci + 3) // 4 * 4
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)
+    b = torch.randn(Co, generator=g) * 0.1
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = F.max_pool2d(torch.relu(F.conv2d(xr, wr, br, stride=stride)), 2, 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    xd = _nhwc(x, CiP).to(DEV)
+    wf, wd = ops.conv_pack_weights(w.to(DEV), CiP)
+    pooled, amax = ops.conv_fwd(xd, wf, b.to(DEV), stride)
+    torch.cuda.synchronize()
+    check(f"conv fwd {B,H,W,Ci,Co,stride}", pooled.permute(0, 3, 1, 2), yr, 3e-6 * math.sqrt(9 * Ci))
+    dead = (amax == 4)
+    assert bool(((pooled == 0) == dead).all()), "arg-max code 4 must mark exactly the zero outputs"
+
+    dyd = _nhwc(dy).to(DEV)
+    dx = ops.conv_dgrad(dyd, amax, wd, xd.shape, stride)
+    dw = torch.empty(Co, Ci, 3, 3, device=DEV)
+    db = torch.empty(Co, device=DEV)
+    ops.conv_wgrad(xd, dyd, amax, dw, db, stride)
+    torch.cuda.synchronize()
+    check("conv dgrad", dx[..., :Ci].permute(0, 3, 1, 2), xr.grad, 5e-6 * math.sqrt(9 * Co))
+    if CiP != Ci:
+        assert float(dx[..., Ci:].abs().max()) == 0.0
+    check("conv wgrad", dw, wr.grad, 2e-5)
+    check("conv bias grad", db, br.grad, 2e-5)
+
+
+def test_nchw_to_nhwc4():
+    ops = _ops()
+    x = torch.randn(2, 3, 9, 11)
+    y = ops.nchw_to_nhwc4(x.to(DEV)).cpu()
+    assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1)) and float(y[..., 3].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- point-wise / reductions
+def test_l2norm_fwd_bwd():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    u = torch.randn(37, 32, generator=g)
+    u[5] = 0.0   # an all-zero pixel: norm 0 -> vn 0, finite gradient
+    ur = u.double().requires_grad_(True)
+    vr = ur / (ur.norm(p=2, dim=1, keepdim=True).expand_as(ur) + 1e-12)
+    dv = torch.randn(37, 32, generator=g)
+    vr.backward(dv.double())
+    vn, norm = ops.l2norm_fwd(u.to(DEV), 0.0, 0)
+    du = ops.l2norm_bwd(dv.to(DEV), vn, norm, 0.0, 0)
+    torch.cuda.synchronize()
+    check("l2norm fwd", vn, vr, 2e-6)
+    mask = torch.ones(37, dtype=torch.bool); mask[5] = False
+    check("l2norm bwd", du[mask.to(DEV)], ur.grad[mask], 5e-6)
+    assert bool(torch.isfinite(du).all())
+
+
+def test_embed_tanh_fwd_bwd():
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    V, E, B, T = 20, 12, 5, 4
+    emb = torch.randn(V, E, generator=g)
+    q = torch.randint(0, V, (B, T), generator=g)
+    q[0, 1] = 0
+    er = emb.double().requires_grad_(True)
+    xr = torch.tanh(F.embedding(q, er, padding_idx=0)).transpose(0, 1)   # [T,B,E]
+    dx = torch.randn(T, B, E, generator=g)
+    xr.backward(dx.double())
+    x = ops.embed_tanh_fwd(q.to(DEV), emb.to(DEV), 0.0, 0)
+    demb = torch.zeros(V, E, device=DEV)
+    ops.embed_tanh_bwd(q.to(DEV), x, dx.to(DEV), demb, 0.0, 0)
+    torch.cuda.synchronize()
+    check("embed fwd", x, xr, 2e-6)
+    check("embed bwd", demb, er.grad, 5e-6)
+    assert float(demb[0].abs().max()) == 0.0
+
+
+def test_lstm_cell_fwd_bwd():
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    B, H, t = 6, 16, 2
+    q_len = torch.tensor([5, 3, 1, 2, 4, 3])
+    xg, hg = torch.randn(B, 4 * H, generator=g), torch.randn(B, 4 * H, generator=g)
+    c0, h0 = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+    xr = (xg + hg).double().requires_grad_(True)
+    cr = c0.double().requires_grad_(True)
+    hr = h0.double().requires_grad_(True)
+    i, f, gg, o = xr.split(H, dim=1)
+    cn = torch.sigmoid(f) * cr + torch.sigmoid(i) * torch.tanh(gg)
+    hn = torch.sigmoid(o) * torch.tanh(cn)
+    m = (q_len > t).double().unsqueeze(1)
+    c1 = m * cn + (1 - m) * cr
+    h1 = m * hn + (1 - m) * hr
+    dh, dc = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+    (c1 * dc.double() + h1 * dh.double()).sum().backward()
+
+    gates = torch.empty(B, 4 * H, device=DEV)
+    c_out, h_out = torch.empty(B, H, device=DEV), torch.empty(B, H, device=DEV)
+    cf = torch.zeros(B, 2 * H + 4, device=DEV)
+    ops.lstm_cell_fwd(xg.to(DEV), hg.to(DEV), c0.to(DEV), h0.to(DEV), q_len.to(DEV), t, gates, c_out, h_out,
+                      cf[:, 4:], 2 * H + 4)
+    dhd, dcd = dh.clone().to(DEV), dc.clone().to(DEV)
+    dg = torch.empty(B, 4 * H, device=DEV)
+    ops.lstm_cell_bwd(gates, c0.to(DEV), c_out, q_len.to(DEV), t, dhd, dcd, dg)
+    torch.cuda.synchronize()
+    check("lstm cell c", c_out, c1, 2e-6)
+    check("lstm cell h", h_out, h1, 2e-6)
+    check("lstm cell c_final", cf[:, 4:4 + H], c1, 2e-6)
+    check("lstm cell dgates", dg, xr.grad, 5e-6)
+    check("lstm cell dc_in", dcd, cr.grad, 5e-6)
+    check("lstm cell dh passthrough", dhd, hr.grad, 5e-6)
+
+
+def test_attention_score_and_apply():
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    B, P, C, mid, G = 3, 9, 32, 24, 2
+    xs = torch.relu(torch.randn(B * P, mid, generator=g))
+    wx, bx = torch.randn(G, mid, generator=g), torch.randn(G, generator=g)
+    vn = torch.randn(B, P, C, generator=g)
+    xr = xs.double().requires_grad_(True)
+    wr, br, vr = wx.double().requires_grad_(True), bx.double().requires_grad_(True), vn.double().requires_grad_(True)
+    sc = (xr @ wr.t() + br).reshape(B, P, G).permute(0, 2, 1)          # [B,G,P]
+    pr = torch.softmax(sc, dim=-1)
+    out = torch.einsum("bgp,bpc->bgc", pr, vr).reshape(B, G * C)
+    dout = torch.randn(B, G * C + 8, generator=g)
+    (out * dout[:, :G * C].double()).sum().backward()
+
+    score = ops.att_score_fwd(xs.to(DEV), wx.to(DEV), bx.to(DEV), B, P, 0.0, 0)
+    outd = torch.zeros(B, G * C + 8, device=DEV)
+    probs = ops.att_apply_fwd(score, vn.to(DEV), outd, G * C + 8)
+    dscore, dvn = ops.att_apply_bwd(dout.to(DEV), G * C + 8, probs, vn.to(DEV))
+    xs_io = xs.clone().to(DEV)
+    dwx_part, dq_part, RS = ops.att_score_bwd(dscore, wx.to(DEV), xs_io, B, P, 0.0, 0)
+    dwx = torch.empty(G * mid, device=DEV)
+    ops.colsum(dwx_part, B * RS, G * mid, dwx)
+    dq = torch.empty(B, mid, device=DEV)
+    ops.sum_parts(dq_part, dq, B, RS, mid)
+    dbx = torch.empty(G, device=DEV)
+    ops.sum_bgp(dscore, dbx)
+    torch.cuda.synchronize()
+    check("att score", score, sc, 3e-6)
+    check("att probs", probs, pr, 3e-6)
+    check("att weighted", outd[:, :G * C], out, 3e-6)
+    check("att dvn", dvn, vr.grad, 1e-5)
+    # xr.grad is zero where xs == 0 only through the relu of the caller; here dxpre masks xs > 0
+    check("att dxpre", xs_io, xr.grad * (xs > 0).double(), 1e-5)
+    check("att dwx", dwx.view(G, mid), wr.grad, 1e-5)
+    check("att dbx", dbx, br.grad, 1e-5)
+    check("att dq(+)", dq, (xr.grad * (xs > 0).double()).reshape(B, P, mid).sum(1), 1e-5)
+
+
+def test_softce_loss_score_and_grad():
+    from oracle import vqa_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    B, A = 7, 50
+    logits = torch.randn(B, A, generator=g) * 3
+    a_idx = torch.zeros(B, 3, dtype=torch.int64)
+    a_val = torch.zeros(B, 3, dtype=torch.int64)
+    for b in range(B):
+        k = 1 + b % 3
+        a_idx[b, :k] = torch.randperm(A, generator=g)[:k] + 1
+        a_val[b, :k] = torch.randint(1, 6, (k,), generator=g)
+    a_idx[2, 0] = int(logits[2].argmax()) + 1            # one sure hit for the score
+    lr = logits.double().requires_grad_(True)
+    loss = O.soft_ce_loss(lr, a_idx, a_val)
+    loss.backward()
+    ld = A + 2
+    ld_buf = torch.zeros(B, ld, device=DEV); ld_buf[:, :A] = logits.to(DEV)
+    dl = torch.zeros(B, ld, device=DEV)
+    loss_rows, score_rows = ops.softce(ld_buf, ld, a_idx.to(DEV), a_val.to(DEV), A, 1.0 / B, dl, ld)
+    torch.cuda.synchronize()
+    check("softce loss", loss_rows.sum(), loss, 3e-6)
+    check("softce dlogits", dl[:, :A], lr.grad, 1e-5)
+    check("vqa score", score_rows.sum(), O.batch_accuracy(logits, a_idx, a_val), 1e-6)
+
+
+def test_colsum_masked_and_adam_and_misc():
+    from oracle import vqa_oracle as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(1000, 70, generator=g)
+    mask = torch.randint(0, 5, (1000, 70), generator=g).to(torch.uint8)
+    out = torch.ones(70, device=DEV)
+    ops.colsum(x.to(DEV), 1000, 70, out, mask=mask.to(DEV), accumulate=True)
+    torch.cuda.synchronize()
+    check("colsum masked+acc", out, (x.double() * (mask != 4)).sum(0) + 1, 1e-5)
+    # Adam against the oracle (== torch.optim.Adam, tests/test_oracle_golden.py)
+    p, gr = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    m, v = torch.zeros(1000), torch.zeros(1000)
+    pd, md, vd = p.clone().to(DEV), m.clone().to(DEV), v.clone().to(DEV)
+    for step in (1, 2, 3):
+        lr = O.learning_rate(5e-4, step - 1)
+        O.adam_step(p, gr, m, v, step, lr)
+        ops.adam(pd, gr.to(DEV), md, vd, lr, step)
+    torch.cuda.synchronize()
+    check("adam", pd, p, 1e-6)
+    # relu+dropout backward with p = 0, add
+    y, dy = torch.randn(999, generator=g), torch.randn(999, generator=g)
+    dx = torch.empty(999, device=DEV)
+    ops.relu_drop_bwd(y.to(DEV), dy.to(DEV), dx, 0.0, 0)
+    s = torch.empty(999, device=DEV)
+    ops.add(y.to(DEV), dy.to(DEV), s)
+    torch.cuda.synchronize()
+    check("relu bwd", dx, dy * (y > 0), 0.0)
+    check("add", s, y + dy, 0.0)
+
+
+def test_dropout_statistics_and_determinism():
+    ops = _ops()
+    x = torch.ones(1 << 20, device=DEV)
+    y1 = ops.dropout(x, 0.3, 1234)
+    y2 = ops.dropout(x, 0.3, 1234)
+    y3 = ops.dropout(x, 0.3, 1235)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)                       # same seed, same mask (backward regenerates it)
+    assert not torch.equal(y1, y3)
+    keep = float((y1 > 0).float().mean())
+    assert abs(keep - 0.7) < 3e-3, keep
+    vals = torch.unique(y1)
+    assert len(vals) == 2 and abs(float(vals.max()) - 1 / 0.7) < 1e-6
+    assert abs(float(y1.mean()) - 1.0) < 5e-3        # inverted dropout keeps the mean

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — VQA train-step throughput on MI355X (BASELINE.json metric: VQA samples/sec).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + soft-target CE + backward + gradient all-reduce (N > 1) + Adam on one synthetic
+batch that is already resident in HBM: BASELINE.json configs[1] (batch 256 per GPU, 224x224 images,
+14-token questions, 1000-way answer head, fp32), train mode with all dropout sites active, random-init
+weights of the reference architecture (config.yaml:51-74).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def reference_cfg(answers: int) -> dict:
+    """train: section of the reference's config/config.yaml:51-74 (max_answers per BASELINE.json)."""
+    return {
+        "text": {"question_features": 1024, "embedding_features": 300, "dropout": 0.3,
+                 "num_lstm_layers": 1, "bidirectional": True},
+        "image": {"kernel_size": 3, "dropout": 0.3, "num_channels": [3, 64, 128, 256], "stride": 1,
+                  "do_skip_connection": False},
+        "attention": {"hidden_dim": 1024, "glimpses": 2, "do_option": "+", "dropout": 0.3},
+        "classifier": {"hidden_dim": 1024, "dropout": 0.3},
+        "max_answers": answers,
+    }
+
+
+def synthetic_batch(B, S, T, V, A, seed, full_len=True, kmax=3):
+    """7-tuple in the dataset layout (data_preprocessing.py:74-87): SURVEY.md §8d synthetic inputs."""
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(B, 3, S, S, generator=g)
+    q_len = torch.full((B,), T, dtype=torch.int64) if full_len else torch.randint(1, T + 1, (B,), generator=g)
+    q = torch.randint(1, V, (B, T), generator=g) * (torch.arange(T)[None, :] < q_len[:, None])
+    a_len = torch.randint(1, kmax + 1, (B,), generator=g)
+    a_idx = torch.zeros(B, kmax, dtype=torch.int64)
+    a_val = torch.zeros(B, kmax, dtype=torch.int64)
+    col = torch.arange(kmax)[None, :]
+    a_idx = (torch.rand(B, A, generator=g).argsort(dim=1)[:, :kmax] + 1) * (col < a_len[:, None])
+    a_val = torch.randint(1, 4, (B, kmax), generator=g) * (col < a_len[:, None])
+    return v, q, a_idx, a_val, a_len, torch.arange(B), q_len
+
+
+def conv_shapes(S, channels, stride=1):
+    """[(Cin, Cout, Ho, Wo)] per conv block, for the algorithmic FLOP counts."""
+    out, H = [], S
+    for ci, co in zip(channels[:-1], channels[1:]):
+        Ho = (H - 3) // stride + 1
+        out.append((ci, co, Ho, Ho))
+        H = Ho // 2
+    return out, H
+
+
+def step_flops_per_sample(cfg, S, T):
+    """2*MACs of every contraction, forward + backward (wgrad + dgrad, no dgrad for conv0)."""
+    ch = cfg["image"]["num_channels"]
+    shapes, g = conv_shapes(S, ch, cfg["image"]["stride"])
+    fwd = 0.0
+    conv0 = 0.0
+    for i, (ci, co, Ho, Wo) in enumerate(shapes):
+        m = Ho * Wo * co * 9 * ci
+        fwd += m
+        if i == 0:
+            conv0 = m
+    P = g * g
+    E, H = cfg["text"]["embedding_features"], cfg["text"]["question_features"]
+    nd = 2 if cfg["text"]["bidirectional"] else 1
+    mid, G, hid, A = cfg["attention"]["hidden_dim"], cfg["attention"]["glimpses"], cfg["classifier"]["hidden_dim"], cfg["max_answers"]
+    C, Q = ch[-1], nd * H
+    fwd += P * C * mid + P * mid * G + P * G * C                  # v_conv, x_conv, weighted sum
+    fwd += nd * T * (E * 4 * H + H * 4 * H)                       # LSTM
+    fwd += Q * mid + (G * C + Q) * hid + hid * A                  # q_lin, lin1, lin2
+    return 2.0 * (3.0 * fwd - conv0)
+
+
+def cpu_baseline(cfg, V, A, T):
+    """The CPU restatement (oracle, kind 'port') timed on this host: forward + loss + backward + Adam,
+    batch 16 of 224x224 images (BASELINE.json configs[0]); bounded to ~10-30 s."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd import VqaNet
+    B, S = 16, 224
+    torch.manual_seed(1)
+    sd = {k: t.detach().clone() for k, t in VqaNet(cfg, V).state_dict().items()}
+    m = {k: torch.zeros_like(t) for k, t in sd.items()}
+    vv = {k: torch.zeros_like(t) for k, t in sd.items()}
+    batch = synthetic_batch(B, S, T, V, A, seed=1)
+    v, q, a_idx, a_val, _, _, q_len = batch
+    times = []
+    t_all = time.time()
+    for it in range(3):
+        t0 = time.time()
+        _, loss, grads = O.loss_and_grads(sd, cfg, v, q, q_len, a_idx, a_val)
+        lr = O.learning_rate(5e-4, it)
+        for k in sd:
+            O.adam_step(sd[k], grads[k], m[k], vv[k], it + 1, lr)
+        times.append(time.time() - t0)
+        if time.time() - t_all > 25:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(B / best, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} train steps (fwd+loss+bwd+Adam) of batch {B}, {S}x{S}, T={T}, A={A}; "
+                      f"best of {max(1, len(times) - 1)} after 1 warm-up; os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE.json configs[1])")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--tokens", type=int, default=14)
+    ap.add_argument("--answers", type=int, default=1000)
+    ap.add_argument("--vocab", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="diagnostic only: dropout off")
+    ap.add_argument("--roofline-kernel", default="conv_wgrad:1",
+                    help="kernel family:tag timed live with HIP events (conv_fwd|conv_dgrad|conv_wgrad : layer)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dl_vqa_amd import VqaNet, _lib
+    from dl_vqa_amd.distributed import DataParallel
+    from dl_vqa_amd.train import FusedAdam, run_batch, update_learning_rate
+
+    lib = _lib.load()
+    assert lib.vqa_device_ok() == 1, "no gfx950 device visible"
+    cfg = reference_cfg(args.answers)
+    B, S, T, V, A = args.batch, args.size, args.tokens, args.vocab, args.answers
+    torch.manual_seed(1)                                   # config.yaml:9 seed
+    model = VqaNet(cfg, V).to(dev)
+    model.train(not args.eval_mode)
+    if world > 1:
+        DataParallel(model)
+    batch = tuple(t.to(dev) for t in synthetic_batch(B, S, T, V, A, seed=1 + rank))
+    opt = FusedAdam(model, lr=5e-4)
+    it = [0]
+
+    def step():
+        loss, score = run_batch(model, None, batch, A, batch_divisor=B * world)
+        opt.zero_grad()
+        update_learning_rate(opt, it[0], 5e-4)
+        loss.backward()
+        opt.step()
+        it[0] += 1
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    fam, tag = args.roofline_kernel.split(":")
+    fam_id = {"gemm": 0, "conv_fwd": 1, "conv_dgrad": 2, "conv_wgrad": 3}[fam]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.vqa_prof_arm(fam_id, int(tag))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    n_launch, tot_ms = ctypes.c_int(0), ctypes.c_float(0.0)
+    lib.vqa_prof_read(ctypes.byref(n_launch), ctypes.byref(tot_ms))
+    lib.vqa_prof_arm(-1, -1)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        shapes, _ = conv_shapes(S, cfg["image"]["num_channels"], cfg["image"]["stride"])
+        ci, co, Ho, Wo = shapes[int(tag)] if fam != "gemm" else (0, 0, 0, 0)
+        flops_launch = 2.0 * B * Ho * Wo * co * 9 * ci
+        roofline = None
+        if n_launch.value > 0 and flops_launch > 0:
+            avg_ms = tot_ms.value / n_launch.value
+            ach = flops_launch / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": f"{fam}[conv{tag}]", "achieved": round(ach, 2),
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch.value,
+                        "algorithmic_gflop_per_launch": round(flops_launch / 1e9, 2)}
+        gflop_sample = step_flops_per_sample(cfg, S, T) / 1e9
+        out = {
+            "metric": "VQA samples/sec (train step)", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"VqaNet train step (fwd+softCE+bwd+{'allreduce+' if world > 1 else ''}Adam), "
+                                   f"batch {B}/GPU, {S}x{S} images, {T}-token questions, {A}-way head, "
+                                   f"{'eval' if args.eval_mode else 'train'} mode",
+                       "global_batch": B * world, "image_size": S, "tokens": T, "answers": A, "vocab": V,
+                       "parallelism": f"dp{world}"},
+            "step_gflop_per_sample": round(gflop_sample, 3),
+            "step_mfma_frac": round(value * gflop_sample / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            "final_loss": round(final_loss, 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, V, A, T)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

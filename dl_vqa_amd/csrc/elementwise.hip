@@ -492,9 +492,19 @@ __global__ void relu_drop_bwd_kernel(const float* y, const float* dy, float* dx,
   }
 }
 
-__global__ void add_kernel(const float* a, const float* b, float* y, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    y[i] = a[i] + b[i];
+__global__ void add2d_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy,
+                             int64_t rows, int cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    y[r * ldy + c] = a[r * lda + c] + (b ? b[r * ldb + c] : 0.f);
+  }
+}
+
+__global__ void scale_by_kernel(float* x, int64_t n, const float* s) {
+  const float k = *s;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= k;
 }
 
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1,
@@ -666,10 +676,18 @@ int vqa_relu_drop_bwd(const float* y, const float* dy, float* dx, int64_t n, flo
   return check_hip(hipGetLastError(), "relu_drop_bwd launch");
 }
 
-int vqa_add(const float* a, const float* b, float* y, int64_t n, vqa_stream_t stream) {
-  VQA_REQUIRE(a && b && y, "vqa_add: null pointer");
-  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, a, b, y, n);
-  return check_hip(hipGetLastError(), "add launch");
+int vqa_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy, int64_t rows,
+              int cols, vqa_stream_t stream) {
+  VQA_REQUIRE(a && y && rows > 0 && cols > 0, "vqa_add2d: bad args");
+  hipLaunchKernelGGL(add2d_kernel, dim3(grid_for(rows * cols, 256)), dim3(256), 0, STREAM, a, lda, b, ldb, y, ldy,
+                     rows, cols);
+  return check_hip(hipGetLastError(), "add2d launch");
+}
+
+int vqa_scale_by(float* x, int64_t n, const float* scalar, vqa_stream_t stream) {
+  VQA_REQUIRE(x && scalar && n > 0, "vqa_scale_by: bad args");
+  hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, x, n, scalar);
+  return check_hip(hipGetLastError(), "scale_by launch");
 }
 
 int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

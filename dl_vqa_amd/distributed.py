@@ -1,0 +1,62 @@
+"""Data-parallel training of VqaNet over RCCL (one process per GPU, torch.distributed 'nccl').
+
+The reference is single-GPU (main.py:23 pins CUDA_VISIBLE_DEVICES=0); SURVEY.md §8e defines the
+sharding: the global minibatch is split by sample, every rank divides its loss by the GLOBAL batch,
+and parameter gradients are SUM-all-reduced.  Gradients live in one flat buffer ordered as backward
+produces them (classifier, attention, text, image), so each group is one contiguous bucket whose
+all-reduce is launched as soon as its kernels are enqueued and overlaps the rest of backward (the
+convolution gradients, the longest tail).  xGMI is point-to-point, so few large buckets (4) are
+used rather than many small ones.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+GROUPS = ("classifier", "attention", "text", "image")
+
+
+class DataParallel:
+    """Gradient synchroniser attached to a model that exposes flat_buffers() / group_range()."""
+
+    def __init__(self, model, process_group: Optional[dist.ProcessGroup] = None, broadcast: bool = True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.model = model
+        self.pg = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self._handles: List = []
+        model._grad_sync = self
+        model._seed_rank = self.rank            # different dropout masks per rank
+        if broadcast:
+            flat_p, _, _ = model.flat_buffers()
+            dist.broadcast(flat_p, src=0, group=process_group)
+
+    # called by the backward schedule after the kernels of `group` have been enqueued
+    def bucket_ready(self, model, group: str) -> None:
+        _, flat_g, _ = model.flat_buffers()
+        lo, hi = model.group_range(group)
+        self._handles.append(dist.all_reduce(flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self, model) -> None:
+        for h in self._handles:
+            h.wait()                            # stream-ordered on NCCL: no host block
+        self._handles = []
+
+    def __call__(self, *args, **kwargs):
+        return self.model(*args, **kwargs)
+
+    def __getattr__(self, name):
+        return getattr(self.model, name)
+
+
+def shard_batch(batch_data, rank: int, world_size: int):
+    """Split a global 7-tuple (data_preprocessing.py:74-87 layout) evenly by sample."""
+    B = batch_data[0].shape[0]
+    assert B % world_size == 0, "global batch must divide evenly over ranks"
+    per = B // world_size
+    sl = slice(rank * per, (rank + 1) * per)
+    return tuple(t[sl] for t in batch_data)

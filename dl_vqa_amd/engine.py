@@ -1,0 +1,264 @@
+"""Forward / backward schedule of the VqaNet hot path over the HIP kernels.
+
+This is the host-side mirror of ``models/model.py:53-67`` (VqaNet.forward) and of what autograd
+would do for it: a fixed sequence of C-ABI calls (dl_vqa_amd.ops) on torch's current HIP stream.
+torch only provides the buffers.  Layouts: images NHWC (channels padded to 4), question
+activations time-major [T][B][*], the classifier input `combined` = [weighted v | c_fwd | c_bwd].
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+# dropout sites (models/model.py:84,156,185,186,194,201,204)
+SITE_IMAGE, SITE_TEXT, SITE_ATT_V, SITE_ATT_Q, SITE_ATT_X, SITE_CLS1, SITE_CLS2 = 1, 2, 3, 4, 5, 6, 7
+_MASK64 = (1 << 64) - 1
+
+
+def _site_seed(base: int, site: int) -> int:
+    return (base * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & _MASK64
+
+
+class Engine:
+    def __init__(self, cfg: dict, embedding_tokens: int):
+        t, i, a, c = cfg["text"], cfg["image"], cfg["attention"], cfg["classifier"]
+        self.V = embedding_tokens
+        self.E = t["embedding_features"]
+        self.H = t["question_features"]
+        self.ndir = 2 if t["bidirectional"] else 1
+        if t["num_lstm_layers"] != 1:
+            raise NotImplementedError("num_lstm_layers != 1 (the reference notes it 'needs change of code' too, "
+                                      "config.yaml:55)")
+        self.channels = list(i["num_channels"])
+        self.L = len(self.channels) - 1
+        self.stride = i["stride"]
+        if i["kernel_size"] != 3:
+            raise NotImplementedError("only kernel_size=3 (config.yaml:58) has a HIP kernel")
+        self.mid = a["hidden_dim"]
+        self.G = a["glimpses"]
+        self.do_option = a["do_option"]
+        if self.do_option not in ("+",):
+            raise NotImplementedError(f"attention do_option {self.do_option!r}: only '+' (config.yaml:68) is "
+                                      "implemented on the HIP path so far")
+        self.hid = c["hidden_dim"]
+        self.A = cfg["max_answers"]
+        self.p_text, self.p_image, self.p_att, self.p_cls = t["dropout"], i["dropout"], a["dropout"], c["dropout"]
+        self.C = self.channels[-1]
+        self.Q = self.ndir * self.H
+        self.GC = self.G * self.C
+        self.Dc = self.GC + self.Q
+        for name, val in (("embedding_features", self.E), ("question_features", self.H), ("hidden_dim(att)", self.mid),
+                          ("hidden_dim(cls)", self.hid)) + tuple((f"num_channels[{k}]", ch) for k, ch in
+                                                                 enumerate(self.channels[1:], 1)):
+            if val % 4:
+                raise ValueError(f"{name}={val}: the HIP kernels need multiples of 4 (16-byte vector loads)")
+        if self.channels[0] > 4:
+            raise ValueError("input images with more than 4 channels are not supported")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, P: Dict[str, Tensor], v: Tensor, q: Tensor, q_len: Tensor, training: bool, seed: int,
+                keep: bool):
+        """Returns (logits [B,A], ctx or None). `keep` = save what backward needs."""
+        assert v.is_cuda and v.dtype == torch.float32 and v.dim() == 4, "v must be a float32 CUDA tensor [B,C,S,S]"
+        v = v.contiguous()
+        q = q.to(device=v.device, dtype=torch.int64).contiguous()
+        q_len = q_len.to(device=v.device, dtype=torch.int64).contiguous()
+        dev = v.device
+        B, T = q.shape
+        E, H, G, C, mid, hid, A, Dc, GC, Q = self.E, self.H, self.G, self.C, self.mid, self.hid, self.A, self.Dc, self.GC, self.Q
+        tr = bool(training)
+        sd = lambda site: _site_seed(seed, site)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+
+        # ---- image encoder: conv+relu+pool x L (models/model.py:79-84)
+        acts = [ops.nchw_to_nhwc4(v)]
+        idxs, wds = [], []
+        for l in range(self.L):
+            w = P[f"image.conv{l}.weight"]
+            assert w.shape[0] == self.channels[l + 1]
+            wf, wd = ops.conv_pack_weights(w, acts[-1].shape[3], need_wd=(keep and l > 0))
+            pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l)
+            acts.append(pooled)
+            idxs.append(am)
+            wds.append(wd)
+        pooled = acts[-1]
+        Pn = pooled.shape[1] * pooled.shape[2]
+        # ---- image dropout + L2 normalisation over channels (model.py:84,56)
+        p_img = self.p_image if tr else 0.0
+        vn, norm = ops.l2norm_fwd(pooled, p_img, sd(SITE_IMAGE))
+
+        # ---- question encoder (model.py:155-166)
+        p_txt = self.p_text if tr else 0.0
+        x_emb = ops.embed_tanh_fwd(q, P["text.embedding.weight"], p_txt, sd(SITE_TEXT))       # [T,B,E]
+        combined = new(B, Dc)
+        lstm = []
+        for d in range(self.ndir):
+            sfx = "_reverse" if d else ""
+            w_ih, w_hh = P["text.lstm.weight_ih_l0" + sfx], P["text.lstm.weight_hh_l0" + sfx]
+            xg = new(T * B, 4 * H)
+            ops.gemm(x_emb, w_ih, xg, T * B, 4 * H, E, bias1=P["text.lstm.bias_ih_l0" + sfx],
+                     bias2=P["text.lstm.bias_hh_l0" + sfx], tag=10)
+            Hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=dev)
+            Cs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=dev)
+            gates = new(T, B, 4 * H)
+            hg = new(B, 4 * H)
+            order = range(T) if d == 0 else range(T - 1, -1, -1)
+            for n, t in enumerate(order):
+                si, so = (t, t + 1) if d == 0 else (t + 1, t)
+                ops.gemm(Hs[si], w_hh, hg, B, 4 * H, H, tag=11)
+                last = n == T - 1
+                ops.lstm_cell_fwd(xg[t * B:(t + 1) * B], hg, Cs[si], Hs[si], q_len, t, gates[t], Cs[so], Hs[so],
+                                  combined[:, GC + d * H:] if last else None, Dc)
+            lstm.append(SimpleNamespace(gates=gates, Hs=Hs, Cs=Cs))
+        qf = combined[:, GC:]
+
+        # ---- attention (model.py:183-195): v' = v_conv(drop(v)), q' = q_lin(drop(q)), x = relu(v' + q')
+        p_att = self.p_att if tr else 0.0
+        if p_att > 0:
+            v_in = ops.dropout(vn, p_att, sd(SITE_ATT_V))
+            q_in = new(B, Q)
+            ops.add2d(qf, Dc, None, 0, q_in, Q, B, Q)
+            ops.dropout(q_in, p_att, sd(SITE_ATT_Q), out=q_in)
+            ld_q = Q
+        else:
+            v_in, q_in, ld_q = vn, qf, Dc
+        qp = new(B, mid)
+        ops.gemm(q_in, P["attention.q_lin.weight"], qp, B, mid, Q, lda=ld_q, bias1=P["attention.q_lin.bias"], tag=20)
+        xs = new(B * Pn, mid)
+        ops.gemm(v_in, P["attention.v_conv.weight"], xs, B * Pn, mid, C, rowgroup=qp, rg_div=Pn, rg_op=0, relu=True,
+                 tag=21)
+        wx = P["attention.x_conv.weight"]
+        score = ops.att_score_fwd(xs, wx.view(G, -1), P["attention.x_conv.bias"], B, Pn, p_att, sd(SITE_ATT_X))
+        # ---- softmax over positions + weighted sum (model.py:208-221) -> combined[:, :G*C]
+        probs = ops.att_apply_fwd(score, vn, combined, Dc)
+
+        # ---- classifier (model.py:198-205)
+        p_cls = self.p_cls if tr else 0.0
+        c_in = ops.dropout(combined, p_cls, sd(SITE_CLS1)) if p_cls > 0 else combined
+        h1 = new(B, hid)
+        ops.gemm(c_in, P["classifier.lin1.weight"], h1, B, hid, Dc, bias1=P["classifier.lin1.bias"], relu=True, tag=30)
+        h1d = ops.dropout(h1, p_cls, sd(SITE_CLS2)) if p_cls > 0 else h1
+        logits = new(B, A)
+        ops.gemm(h1d, P["classifier.lin2.weight"], logits, B, A, hid, bias1=P["classifier.lin2.bias"], tag=31)
+
+        if not keep:
+            return logits, None
+        ctx = SimpleNamespace(B=B, T=T, Pn=Pn, q=q, q_len=q_len, acts=acts, idxs=idxs, wds=wds, vn=vn, norm=norm,
+                              x_emb=x_emb, lstm=lstm, v_in=v_in, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
+                              c_in=c_in, h1=h1, h1d=h1d, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
+                              seed=seed, stages=dict(pooled=pooled, score=score, combined=combined))
+        return logits, ctx
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, P: Dict[str, Tensor], ctx, dlogits: Tensor, Gr: Dict[str, Tensor],
+                 on_ready: Optional[Callable[[str], None]] = None) -> None:
+        """Writes the gradient of every parameter into Gr[name] (caller-owned, same shapes as P).
+
+        `on_ready(group)` is called after the kernels producing a parameter group have been enqueued
+        ('classifier', 'attention', 'text', 'image'): the data-parallel wrapper starts that bucket's
+        all-reduce there, overlapping the rest of backward."""
+        B, T, Pn = ctx.B, ctx.T, ctx.Pn
+        E, H, G, C, mid, hid, A, Dc, GC, Q = self.E, self.H, self.G, self.C, self.mid, self.hid, self.A, self.Dc, self.GC, self.Q
+        dev = dlogits.device
+        sd = lambda site: _site_seed(ctx.seed, site)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        ready = on_ready if on_ready is not None else (lambda group: None)
+
+        # dlogits as a GEMM operand needs a leading dimension that is a multiple of 4
+        ldA = (A + 3) // 4 * 4
+        if ldA != A or not dlogits.is_contiguous() or dlogits.data_ptr() % 16:
+            dl = torch.zeros(B, ldA, dtype=torch.float32, device=dev)
+            ops.add2d(dlogits, dlogits.stride(0), None, 0, dl, ldA, B, A)
+            dlogits = dl
+
+        # ---- classifier
+        ops.gemm(dlogits, ctx.h1d, Gr["classifier.lin2.weight"], A, hid, B, transA=True, transB=False, lda=ldA,
+                 ldb=hid, tag=40)
+        ops.colsum(dlogits, B, A, Gr["classifier.lin2.bias"], ld=ldA)
+        dh1 = new(B, hid)
+        ops.gemm(dlogits, P["classifier.lin2.weight"], dh1, B, hid, A, transB=False, lda=ldA, ldb=hid, tag=41)
+        ops.relu_drop_bwd(ctx.h1, dh1, dh1, ctx.p_cls, sd(SITE_CLS2))
+        ops.gemm(dh1, ctx.c_in, Gr["classifier.lin1.weight"], hid, Dc, B, transA=True, transB=False, lda=hid, ldb=Dc,
+                 tag=42)
+        ops.colsum(dh1, B, hid, Gr["classifier.lin1.bias"])
+        dcomb = new(B, Dc)
+        ops.gemm(dh1, P["classifier.lin1.weight"], dcomb, B, Dc, hid, transB=False, lda=hid, ldb=Dc, tag=43)
+        if ctx.p_cls > 0:
+            ops.dropout(dcomb, ctx.p_cls, sd(SITE_CLS1), out=dcomb)
+        ready("classifier")
+
+        # ---- attention apply + scores
+        dscore, dvn = ops.att_apply_bwd(dcomb, Dc, ctx.probs, ctx.vn)
+        ops.sum_bgp(dscore, Gr["attention.x_conv.bias"])
+        wx = P["attention.x_conv.weight"].view(G, -1)
+        dwx_part, dq_part, RS = ops.att_score_bwd(dscore, wx, ctx.xs, B, Pn, ctx.p_att, sd(SITE_ATT_X))
+        dxpre = ctx.xs                                          # overwritten in place
+        ops.colsum(dwx_part, B * RS, G * mid, Gr["attention.x_conv.weight"])
+        dqp = new(B, mid)
+        ops.sum_parts(dq_part, dqp, B, RS, mid)
+        ops.gemm(dxpre, ctx.v_in, Gr["attention.v_conv.weight"], mid, C, B * Pn, transA=True, transB=False, lda=mid,
+                 ldb=C, tag=44)
+        wv = P["attention.v_conv.weight"]
+        if ctx.p_att > 0:
+            dv_in = new(B * Pn, C)
+            ops.gemm(dxpre, wv, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
+            ops.dropout(dv_in, ctx.p_att, sd(SITE_ATT_V), out=dv_in)
+            ops.add(dvn, dv_in, dvn)
+        else:
+            ops.gemm(dxpre, wv, dvn, B * Pn, C, mid, transB=False, lda=mid, ldb=C, accumulate=True, tag=45)
+        ops.gemm(dqp, ctx.q_in, Gr["attention.q_lin.weight"], mid, Q, B, transA=True, transB=False, lda=mid,
+                 ldb=ctx.ld_q, tag=46)
+        ops.colsum(dqp, B, mid, Gr["attention.q_lin.bias"])
+        wq = P["attention.q_lin.weight"]
+        if ctx.p_att > 0:
+            dq_in = new(B, Q)
+            ops.gemm(dqp, wq, dq_in, B, Q, mid, transB=False, lda=mid, ldb=Q, tag=47)
+            ops.dropout(dq_in, ctx.p_att, sd(SITE_ATT_Q), out=dq_in)
+            ops.add2d(dcomb[:, GC:], Dc, dq_in, Q, dcomb[:, GC:], Dc, B, Q)
+        else:
+            ops.gemm(dqp, wq, dcomb[:, GC:], B, Q, mid, transB=False, lda=mid, ldb=Q, ldc=Dc, accumulate=True, tag=47)
+        ready("attention")
+
+        # ---- LSTM (BPTT over the masked steps), embedding
+        dx_emb = new(T * B, E)
+        for d in range(self.ndir):
+            sfx = "_reverse" if d else ""
+            st = ctx.lstm[d]
+            w_ih, w_hh = P["text.lstm.weight_ih_l0" + sfx], P["text.lstm.weight_hh_l0" + sfx]
+            dc = new(B, H)
+            ops.add2d(dcomb[:, GC + d * H:], Dc, None, 0, dc, H, B, H)
+            dh = torch.zeros(B, H, dtype=torch.float32, device=dev)
+            dgates = new(T, B, 4 * H)
+            order = range(T - 1, -1, -1) if d == 0 else range(T)
+            for n, t in enumerate(order):
+                si, so = (t, t + 1) if d == 0 else (t + 1, t)
+                ops.lstm_cell_bwd(st.gates[t], st.Cs[si], st.Cs[so], ctx.q_len, t, dh, dc, dgates[t])
+                if n != T - 1:
+                    ops.gemm(dgates[t], w_hh, dh, B, H, 4 * H, transB=False, lda=4 * H, ldb=H, accumulate=True, tag=50)
+            h_in = st.Hs[0:T] if d == 0 else st.Hs[1:T + 1]
+            ops.gemm(dgates, h_in, Gr["text.lstm.weight_hh_l0" + sfx], 4 * H, H, T * B, transA=True, transB=False,
+                     lda=4 * H, ldb=H, tag=51)
+            ops.gemm(dgates, ctx.x_emb, Gr["text.lstm.weight_ih_l0" + sfx], 4 * H, E, T * B, transA=True, transB=False,
+                     lda=4 * H, ldb=E, tag=52)
+            ops.colsum(dgates, T * B, 4 * H, Gr["text.lstm.bias_ih_l0" + sfx])
+            ops.add2d(Gr["text.lstm.bias_ih_l0" + sfx], 4 * H, None, 0, Gr["text.lstm.bias_hh_l0" + sfx], 4 * H, 1, 4 * H)
+            ops.gemm(dgates, w_ih, dx_emb, T * B, E, 4 * H, transB=False, lda=4 * H, ldb=E, accumulate=(d > 0), tag=53)
+        demb = Gr["text.embedding.weight"]
+        demb.zero_()
+        ops.embed_tanh_bwd(ctx.q, ctx.x_emb, dx_emb, demb, ctx.p_txt, sd(SITE_TEXT))
+        ready("text")
+
+        # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first
+        dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE)).view_as(ctx.acts[-1])
+        for l in range(self.L - 1, -1, -1):
+            ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
+                           self.stride, tag=l)
+            if l > 0:
+                dP = ops.conv_dgrad(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride, tag=l)
+        ready("image")

@@ -213,9 +213,19 @@ def relu_drop_bwd(y, dy, dx, p: float, seed: int):
     return dx
 
 
-def add(a, b, out):
-    call("vqa_add", ptr(a), ptr(b), ptr(out), a.numel(), stream())
+def add2d(a, lda, b, ldb, out, ldo, rows, cols):
+    """out[r, c] = a[r, c] + (b[r, c] if b is not None else 0) on strided row-major views."""
+    call("vqa_add2d", ptr(a), lda, ptr(b), ldb, ptr(out), ldo, rows, cols, stream())
     return out
+
+
+def add(a, b, out):
+    return add2d(a, a.numel(), b, a.numel(), out, a.numel(), 1, a.numel())
+
+
+def scale_by(x, scalar_dev):
+    call("vqa_scale_by", ptr(x), x.numel(), ptr(scalar_dev), stream())
+    return x
 
 
 def adam(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

@@ -162,8 +162,13 @@ int vqa_sum_parts(const float* part, float* out, int batch, int parts, int cols,
 /* dx = dy * dropmask * (y > 0): backward of dropout(relu(.)) given y = relu output (model.py:201-204) */
 int vqa_relu_drop_bwd(const float* y, const float* dy, float* dx, int64_t n, float p, uint64_t seed,
                       vqa_stream_t stream);
-/* y = a + b (element-wise; in-place allowed) */
-int vqa_add(const float* a, const float* b, float* y, int64_t n, vqa_stream_t stream);
+/* y[r*ldy + c] = a[r*lda + c] + (b ? b[r*ldb + c] : 0) for r < rows, c < cols (strided add / copy;
+ * in-place allowed): gradient joins such as d(combined) = d(cat[v, q]) (models/model.py:64). */
+int vqa_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y, int64_t ldy,
+              int64_t rows, int cols, vqa_stream_t stream);
+
+/* x[i] *= *scalar (scalar is a DEVICE pointer): chains an upstream loss gradient without a host sync */
+int vqa_scale_by(float* x, int64_t n, const float* scalar, vqa_stream_t stream);
 
 /* ---- optimiser: torch.optim.Adam defaults over one flat buffer (train.py:55,80) ------------- */
 int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -14,6 +14,7 @@
 // wgrad     out[(ky,kx,ci)][co] = sum over conv-output pixels; split along that (huge) reduction over
 //           workgroups into slabs, then reduced and transposed to the torch layout [Co][Ci][3][3].
 #include "gemm_core.hpp"
+#include "gemm_core.hpp"
 
 namespace vqa {
 
@@ -21,322 +22,7 @@ int colsum_launch(const float* x, int64_t ld, const uint8_t* mask, int64_t rows,
                   int accumulate, float* ws, int64_t ws_bytes, hipStream_t s);
 int64_t colsum_ws_bytes(int64_t rows, int cols);
 
-struct ConvGeom {
-  int B, H, W, CiP, Co, stride, Ho, Wo, Hp, Wp;
-};
-static ConvGeom make_geom(int B, int H, int W, int CiP, int Co, int stride) {
-  ConvGeom g{B, H, W, CiP, Co, stride, 0, 0, 0, 0};
-  g.Ho = (H - 3) / stride + 1;
-  g.Wo = (W - 3) / stride + 1;
-  g.Hp = g.Ho / 2;
-  g.Wp = g.Wo / 2;
-  return g;
-}
-
-// ------------------------------------------------------------------ forward A loader (type R)
-template <int NV>
-struct ConvFwdA {
-  struct Params { const float* x; int H, W, CiP, Hp, Wp, stride, nWin, K; };
-  static constexpr bool kTypeR = true;
-  const float* rowp[NV];
-  bool ok[NV];
-  int W, CiP, K, c4;
-  __device__ __forceinline__ void init(const Params& q, int row0, int tid) {
-    W = q.W; CiP = q.CiP; K = q.K; c4 = 4 * (tid & 7);
-#pragma unroll
-    for (int p = 0; p < NV; ++p) {
-      const int m = row0 + (tid >> 3) + 32 * p;
-      int wl = m >> 2;
-      const int j = m & 3;
-      ok[p] = wl < q.nWin;
-      if (!ok[p]) wl = 0;
-      const int px = wl % q.Wp;
-      const int t = wl / q.Wp;
-      const int py = t % q.Hp;
-      const int b = t / q.Hp;
-      const int y = (2 * py + (j >> 1)) * q.stride, x = (2 * px + (j & 1)) * q.stride;
-      rowp[p] = q.x + ((int64_t)(b * q.H + y) * q.W + x) * q.CiP;
-    }
-  }
-  __device__ __forceinline__ void load(int ks, float4 (&r)[NV]) const {
-    const int kk = ks * BK + c4;
-    const bool kok = kk < K;
-    const int tap = kok ? kk / CiP : 0;
-    const int ci = kk - tap * CiP;
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    const int off = (ky * W + kx) * CiP + ci;
-#pragma unroll
-    for (int p = 0; p < NV; ++p)
-      r[p] = (kok && ok[p]) ? *reinterpret_cast<const float4*>(rowp[p] + off) : f4zero();
-  }
-};
-
-template <class Cfg>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(typename ConvFwdA<Cfg::NVA>::Params pa,
-                                                       typename PlainC<Cfg::NVB>::Params pb,
-                                                       const float* __restrict__ bias, float* pooled,
-                                                       uint8_t* amax, int Co, int tiles_n, int nk) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-  const TileCoord tc = tile_coord(tiles_n);
-  const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
-  ConvFwdA<Cfg::NVA> al; al.init(pa, m0, tid);
-  PlainC<Cfg::NVB> bl; bl.init(pb, n0, tid);
-  f32x16 acc[Cfg::TM][Cfg::TN];
-  acc_zero<Cfg>(acc);
-  gemm_mainloop<Cfg>(al, bl, acc, 0, nk, pa.K, smem);
-
-  const int h = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
-    const int col = n0 + acc_col<Cfg>(wn, j, lane);
-    const float bv = col < Co ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int wl = (m0 + wm * Cfg::WM + 32 * i + 8 * g + 4 * h) >> 2;
-        float best = acc[i][j][4 * g];
-        int a = 0;
-        if (acc[i][j][4 * g + 1] > best) { best = acc[i][j][4 * g + 1]; a = 1; }
-        if (acc[i][j][4 * g + 2] > best) { best = acc[i][j][4 * g + 2]; a = 2; }
-        if (acc[i][j][4 * g + 3] > best) { best = acc[i][j][4 * g + 3]; a = 3; }
-        best += bv;
-        if (wl < pa.nWin && col < Co) {
-          const int64_t o = (int64_t)wl * Co + col;
-          pooled[o] = best > 0.f ? best : 0.f;
-          amax[o] = best > 0.f ? (uint8_t)a : (uint8_t)4;
-        }
-      }
-  }
-}
-
-// ------------------------------------------------------------------ pooled-gradient expansion
-__device__ __forceinline__ float4 route4(const float* dp, const uint8_t* am, int64_t off, int j) {
-  const float4 d = *reinterpret_cast<const float4*>(dp + off);
-  const uchar4 id = *reinterpret_cast<const uchar4*>(am + off);
-  float4 r;
-  r.x = id.x == j ? d.x : 0.f;
-  r.y = id.y == j ? d.y : 0.f;
-  r.z = id.z == j ? d.z : 0.f;
-  r.w = id.w == j ? d.w : 0.f;
-  return r;
-}
-
-// ------------------------------------------------------------------ dgrad A loader (type R)
-template <int NV>
-struct ConvDgradA {
-  struct Params { const float* dp; const uint8_t* am; int H, W, Hp, Wp, Co, stride, rows, K; };
-  static constexpr bool kTypeR = true;
-  Params q;
-  int b[NV], y[NV], x[NV];
-  bool ok[NV];
-  int c4;
-  __device__ __forceinline__ void init(const Params& q_, int row0, int tid) {
-    q = q_; c4 = 4 * (tid & 7);
-#pragma unroll
-    for (int p = 0; p < NV; ++p) {
-      int m = row0 + (tid >> 3) + 32 * p;
-      ok[p] = m < q.rows;
-      if (!ok[p]) m = 0;
-      x[p] = m % q.W;
-      const int t = m / q.W;
-      y[p] = t % q.H;
-      b[p] = t / q.H;
-    }
-  }
-  __device__ __forceinline__ void load(int ks, float4 (&r)[NV]) const {
-    const int kk = ks * BK + c4;
-    const bool kok = kk < q.K;
-    const int tap = kok ? kk / q.Co : 0;
-    const int co = kk - tap * q.Co;
-    const int ky = tap / 3, kx = tap - 3 * ky;
-#pragma unroll
-    for (int p = 0; p < NV; ++p) {
-      int yy = y[p] - ky, xx = x[p] - kx;
-      bool v = kok && ok[p] && yy >= 0 && xx >= 0;
-      if (q.stride == 2) { v = v && !(yy & 1) && !(xx & 1); yy >>= 1; xx >>= 1; }
-      v = v && yy < 2 * q.Hp && xx < 2 * q.Wp;
-      if (v) {
-        const int j = ((yy & 1) << 1) | (xx & 1);
-        const int64_t off = ((int64_t)(b[p] * q.Hp + (yy >> 1)) * q.Wp + (xx >> 1)) * q.Co + co;
-        r[p] = route4(q.dp, q.am, off, j);
-      } else {
-        r[p] = f4zero();
-      }
-    }
-  }
-};
-
-template <class Cfg>
-__global__ __launch_bounds__(256) void conv_dgrad_kernel(typename ConvDgradA<Cfg::NVA>::Params pa,
-                                                         typename PlainC<Cfg::NVB>::Params pb, float* dx,
-                                                         int CiP, int tiles_n, int nk) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-  const TileCoord tc = tile_coord(tiles_n);
-  const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
-  ConvDgradA<Cfg::NVA> al; al.init(pa, m0, tid);
-  PlainC<Cfg::NVB> bl; bl.init(pb, n0, tid);
-  f32x16 acc[Cfg::TM][Cfg::TN];
-  acc_zero<Cfg>(acc);
-  gemm_mainloop<Cfg>(al, bl, acc, 0, nk, pa.K, smem);
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-      const int col = n0 + acc_col<Cfg>(wn, j, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
-        if (row < pa.rows && col < CiP) dx[(int64_t)row * CiP + col] = acc[i][j][r];
-      }
-    }
-}
-
-// ------------------------------------------------------------------ wgrad loaders (type C)
-struct WgradGeom { int H, W, CiP, Hp, Wp, Co, stride, Mtot; };
-
-template <int NV>
-struct WgradA {  // A(i = (ky,kx,ci), m) = x[b][yo*s+ky][xo*s+kx][ci]
-  struct Params { const float* x; WgradGeom g; int KI; };
-  static constexpr bool kTypeR = false;
-  Params q;
-  int ioff[NV];
-  bool iok[NV];
-  int kr;
-  __device__ __forceinline__ void init(const Params& q_, int i0, int tid) {
-    q = q_; kr = tid >> 3;
-#pragma unroll
-    for (int p = 0; p < NV; ++p) {
-      const int i = i0 + 4 * ((tid & 7) + 8 * p);
-      iok[p] = i < q.KI;
-      const int tap = iok[p] ? i / q.g.CiP : 0;
-      const int ci = iok[p] ? i - tap * q.g.CiP : 0;
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      ioff[p] = (ky * q.g.W + kx) * q.g.CiP + ci;
-    }
-  }
-  __device__ __forceinline__ void load(int ks, float4 (&r)[NV]) const {
-    const int m = ks * BK + kr;
-    const bool mok = m < q.g.Mtot;
-    const int Wo2 = 2 * q.g.Wp, Ho2 = 2 * q.g.Hp;
-    const int mm = mok ? m : 0;
-    const int xo = mm % Wo2;
-    const int t = mm / Wo2;
-    const int yo = t % Ho2;
-    const int b = t / Ho2;
-    const float* base = q.x + ((int64_t)(b * q.g.H + yo * q.g.stride) * q.g.W + xo * q.g.stride) * q.g.CiP;
-#pragma unroll
-    for (int p = 0; p < NV; ++p)
-      r[p] = (mok && iok[p]) ? *reinterpret_cast<const float4*>(base + ioff[p]) : f4zero();
-  }
-};
-
-template <int NV>
-struct WgradB {  // B(m, co) = dY routed from the pooled gradient
-  struct Params { const float* dp; const uint8_t* am; WgradGeom g; };
-  static constexpr bool kTypeR = false;
-  Params q;
-  int co[NV];
-  int kr;
-  __device__ __forceinline__ void init(const Params& q_, int n0, int tid) {
-    q = q_; kr = tid >> 3;
-#pragma unroll
-    for (int p = 0; p < NV; ++p) co[p] = n0 + 4 * ((tid & 7) + 8 * p);
-  }
-  __device__ __forceinline__ void load(int ks, float4 (&r)[NV]) const {
-    const int m = ks * BK + kr;
-    const bool mok = m < q.g.Mtot;
-    const int Wo2 = 2 * q.g.Wp, Ho2 = 2 * q.g.Hp;
-    const int mm = mok ? m : 0;
-    const int xo = mm % Wo2;
-    const int t = mm / Wo2;
-    const int yo = t % Ho2;
-    const int b = t / Ho2;
-    const int j = ((yo & 1) << 1) | (xo & 1);
-    const int64_t base = ((int64_t)(b * q.g.Hp + (yo >> 1)) * q.g.Wp + (xo >> 1)) * q.g.Co;
-#pragma unroll
-    for (int p = 0; p < NV; ++p)
-      r[p] = (mok && co[p] < q.g.Co) ? route4(q.dp, q.am, base + co[p], j) : f4zero();
-  }
-};
-
-template <class Cfg>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(typename WgradA<Cfg::NVA>::Params pa,
-                                                         typename WgradB<Cfg::NVB>::Params pb, float* slab,
-                                                         int tiles_n, int nk, int ks_per_split) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-  const TileCoord tc = tile_coord(tiles_n);
-  const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
-  const int split = blockIdx.y;
-  WgradA<Cfg::NVA> al; al.init(pa, m0, tid);
-  WgradB<Cfg::NVB> bl; bl.init(pb, n0, tid);
-  f32x16 acc[Cfg::TM][Cfg::TN];
-  acc_zero<Cfg>(acc);
-  const int ks0 = split * ks_per_split;
-  const int ks1 = min(nk, ks0 + ks_per_split);
-  gemm_mainloop<Cfg>(al, bl, acc, ks0, ks1, pa.g.Mtot, smem);
-  const int Co = pa.g.Co;
-  float* out = slab + (int64_t)split * pa.KI * Co;
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-      const int col = n0 + acc_col<Cfg>(wn, j, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
-        if (row < pa.KI && col < Co) out[(int64_t)row * Co + col] = acc[i][j][r];
-      }
-    }
-}
-
-// slab[split][(ky,kx,ciP)][co]  ->  dw[co][ci][ky][kx]
-__global__ void wgrad_reduce_kernel(const float* slab, float* dw, int splits, int KI, int CiP, int Ci, int Co) {
-  const int total = Co * Ci * 9;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int tap = e % 9;
-  const int t = e / 9;
-  const int ci = t % Ci;
-  const int co = t / Ci;
-  const int64_t src = (int64_t)(tap * CiP + ci) * Co + co;
-  float v = 0.f;
-  for (int s = 0; s < splits; ++s) v += slab[(int64_t)s * KI * Co + src];
-  dw[e] = v;
-}
-
-__global__ void pack_weights_kernel(const float* w, float* wf, float* wd, int Co, int Ci, int CiP) {
-  const int total = 9 * CiP * Co;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  // e indexes wf: [(tap*CiP + ci)][co]
-  const int co = e % Co;
-  const int t = e / Co;
-  const int ci = t % CiP;
-  const int tap = t / CiP;
-  const float v = ci < Ci ? w[((int64_t)co * Ci + ci) * 9 + tap] : 0.f;
-  wf[e] = v;
-  if (wd) wd[((int64_t)tap * Co + co) * CiP + ci] = v;
-}
-
-__global__ void nchw_to_nhwc4_kernel(const float* x, float* y, int C, int64_t HW, int64_t total) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = e / HW, p = e - b * HW;
-    const float* s = x + b * C * HW + p;
-    float4 v;
-    v.x = s[0];
-    v.y = C > 1 ? s[HW] : 0.f;
-    v.z = C > 2 ? s[2 * HW] : 0.f;
-    v.w = C > 3 ? s[3 * HW] : 0.f;
-    reinterpret_cast<float4*>(y)[e] = v;
-  }
-}
+#include "conv_device.inc"
 
 using Cfg128 = TileCfg<128, 128, 2, 2>;
 using Cfg128x64 = TileCfg<128, 64, 2, 2>;
@@ -359,7 +45,7 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_fwd)"); if (rc) return rc; done = true; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::SMEM_BYTES, s, pa, pb, bias, pooled, amax,
-                     g.Co, tiles_n, (K + BK - 1) / BK);
+                     g.Co, tiles_m, tiles_n, (K + BK - 1) / BK);
   return check_hip(hipGetLastError(), "conv_fwd launch");
 }
 
@@ -373,8 +59,8 @@ static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, flo
   auto kern = conv_dgrad_kernel<Cfg>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_dgrad)"); if (rc) return rc; done = true; }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::SMEM_BYTES, s, pa, pb, dx, g.CiP, tiles_n,
-                     (K + BK - 1) / BK);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::SMEM_BYTES, s, pa, pb, dx, g.CiP, tiles_m,
+                     tiles_n, (K + BK - 1) / BK);
   return check_hip(hipGetLastError(), "conv_dgrad launch");
 }
 
@@ -406,8 +92,8 @@ static int launch_wgrad(const float* x, const float* dp, const uint8_t* am, floa
   auto kern = conv_wgrad_kernel<Cfg>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_wgrad)"); if (rc) return rc; done = true; }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(256), Cfg::SMEM_BYTES, s, pa, pb, slab,
-                     p.tiles_n, p.nk, p.ks_per_split);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(256), Cfg::SMEM_BYTES, s, pa, pb, slab,
+                     p.tiles_m, p.tiles_n, p.nk, p.ks_per_split);
   return check_hip(hipGetLastError(), "conv_wgrad launch");
 }
 

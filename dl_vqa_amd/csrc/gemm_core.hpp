@@ -8,16 +8,21 @@
 //   * Operands are staged through LDS in K-major images  As[BK][BM+1], Bs[BK][BN+1]:
 //     an MFMA A/B fragment is ONE dword per lane (lane l: row l&31, k = 2s + (l>>5)), so a
 //     fragment read is a stride-1 ds_read_b32 across 32 lanes: conflict free by construction.
+//     Fragment reads are software pipelined one k2-step ahead of the MFMAs that consume them.
 //   * Two kinds of operand loader fill those images from global memory, both with 16-byte
 //     per-lane loads, 8 lanes covering one 128-byte line:
 //       type R ("k-contiguous rows"):  thread -> (row r, k-chunk c); transposing LDS write
 //       type C ("reduction-major"):    thread -> (k-row kr, m-chunk c); straight LDS write
 //     Row addresses come from a functor, which is how implicit-im2col (conv forward), the
 //     max-pool-routed gradient (conv dgrad / wgrad) and plain matrices share one main loop.
-//   * Register-staged double buffering: the global loads of K-step s+1 are issued before the
-//     MFMAs of step s and written to the other LDS buffer after them; one barrier per K-step.
-//     fp32 MFMA is 64 cycles per instruction per SIMD, so one K-step (BK = 32) is >= 1024
-//     MFMA cycles per wave, which covers an HBM round trip.
+//   * A loader has two phases: issue(ks) computes addresses and issues UNCONDITIONAL 16-byte loads
+//     (out-of-range rows/chunks are clamped to a valid address) into a Raw register set; finish()
+//     applies masks / arg-max routing when the data is written to LDS.  Keeping every load
+//     unconditional and every use late is what lets the loads of K-step s+1 stay in flight under
+//     the MFMAs of step s (a predicated load makes hipcc branch and wait per load).
+//   * Register-staged double buffering: one barrier per K-step.  fp32 MFMA is 64 cycles per
+//     instruction per SIMD, so one K-step (BK = 32) is >= 1024 MFMA cycles per wave, which covers
+//     an HBM round trip.
 #pragma once
 #include "common.hpp"
 
@@ -66,26 +71,27 @@ __device__ __forceinline__ void lds_store_C(float* s, const float4 (&r)[NV], int
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// Guarded 16-byte load of elements [k, k+4) of a row that holds `kmax` valid elements.
-__device__ __forceinline__ float4 load4_guard(const float* p, int k, int kmax) {
-  if (k + 3 < kmax) return *reinterpret_cast<const float4*>(p + k);
-  float4 v = f4zero();
-  if (k < kmax) v.x = p[k];
-  if (k + 1 < kmax) v.y = p[k + 1];
-  if (k + 2 < kmax) v.z = p[k + 2];
+// Zero the elements of a 16-byte chunk that lie at or beyond `len` (chunk starts at element e0).
+__device__ __forceinline__ float4 mask4(float4 v, bool on, int e0, int len) {
+  v.x = (on && e0 < len) ? v.x : 0.f;
+  v.y = (on && e0 + 1 < len) ? v.y : 0.f;
+  v.z = (on && e0 + 2 < len) ? v.z : 0.f;
+  v.w = (on && e0 + 3 < len) ? v.w : 0.f;
   return v;
 }
 
 // ---------------------------------------------------------------- plain matrix loaders
-// Type R over a row-major matrix X[rows][K] (ld floats per row): used for A=[M][K] and B=[N][K].
+// Both require ld >= roundup4(row length): a 16-byte load never leaves the row's allocation.
+// Type R over a row-major matrix X[rows][K]: used for A=[M][K] and B=[N][K].
 template <int NV>
 struct PlainR {
   struct Params { const float* p; int64_t ld; int rows; int K; };
+  struct Raw { float4 v[NV]; int k; };
   static constexpr bool kTypeR = true;
   const float* rowp[NV];
   bool ok[NV];
   int K, c4;
-  __device__ __forceinline__ void init(const Params& q, int row0, int tid) {
+  __device__ __forceinline__ void init(const Params& q, int row0, int tid, int /*ks0*/) {
     K = q.K; c4 = 4 * (tid & 7);
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
@@ -94,10 +100,16 @@ struct PlainR {
       rowp[p] = q.p + (int64_t)(ok[p] ? r : 0) * q.ld;
     }
   }
-  __device__ __forceinline__ void load(int ks, float4 (&r)[NV]) const {
+  __device__ __forceinline__ void issue(int ks, Raw& r) {
     const int k = ks * BK + c4;
+    const int kc = k < K ? k : 0;
+    r.k = k;
 #pragma unroll
-    for (int p = 0; p < NV; ++p) r[p] = ok[p] ? load4_guard(rowp[p], k, K) : f4zero();
+    for (int p = 0; p < NV; ++p) r.v[p] = *reinterpret_cast<const float4*>(rowp[p] + kc);
+  }
+  __device__ __forceinline__ void finish(const Raw& r, float4 (&o)[NV]) const {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) o[p] = mask4(r.v[p], ok[p], r.k, K);
   }
 };
 
@@ -105,79 +117,96 @@ struct PlainR {
 template <int NV>
 struct PlainC {
   struct Params { const float* p; int64_t ld; int cols; int K; };
+  struct Raw { float4 v[NV]; bool kok; };
   static constexpr bool kTypeR = false;
   const float* base;
   int64_t ld;
   int K, cols, col0, kr;
-  __device__ __forceinline__ void init(const Params& q, int col0_, int tid) {
+  __device__ __forceinline__ void init(const Params& q, int col0_, int tid, int /*ks0*/) {
     base = q.p; ld = q.ld; K = q.K; cols = q.cols; col0 = col0_ + 4 * (tid & 7); kr = tid >> 3;
   }
-  __device__ __forceinline__ void load(int ks, float4 (&r)[NV]) const {
+  __device__ __forceinline__ void issue(int ks, Raw& r) {
     const int k = ks * BK + kr;
-    const float* row = base + (int64_t)k * ld;
+    r.kok = k < K;
+    const float* row = base + (int64_t)(r.kok ? k : 0) * ld;
 #pragma unroll
-    for (int p = 0; p < NV; ++p) r[p] = (k < K) ? load4_guard(row, col0 + 32 * p, cols) : f4zero();
+    for (int p = 0; p < NV; ++p) {
+      const int c = col0 + 32 * p;
+      r.v[p] = *reinterpret_cast<const float4*>(row + (c < cols ? c : 0));
+    }
+  }
+  __device__ __forceinline__ void finish(const Raw& r, float4 (&o)[NV]) const {
+#pragma unroll
+    for (int p = 0; p < NV; ++p) o[p] = mask4(r.v[p], r.kok, col0 + 32 * p, cols);
   }
 };
 
 // ---------------------------------------------------------------- the main loop
-template <class Cfg>
-__device__ __forceinline__ void mma_kstep(const float* As, const float* Bs,
-                                          f32x16 (&acc)[Cfg::TM][Cfg::TN], int wm, int wn, int lane,
-                                          int kvalid) {
+// NS k2-steps (2 k each) from one LDS image; fragment reads run one step ahead of the MFMAs.
+template <class Cfg, int NS>
+__device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x16 (&acc)[Cfg::TM][Cfg::TN],
+                                          int wm, int wn, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
   const float* ap = As + h * Cfg::LDA + wm * Cfg::WM + l31;
   const float* bp = Bs + h * Cfg::LDB + wn * Cfg::WN + l31;
+  float a[2][Cfg::TM], b[2][Cfg::TN];
 #pragma unroll
-  for (int g = 0; g < BK / 8; ++g) {
-    if (g * 8 < kvalid) {  // block-uniform: skips all-zero tails of the last K-step
+  for (int i = 0; i < Cfg::TM; ++i) a[0][i] = ap[32 * i];
 #pragma unroll
-      for (int s = g * 4; s < g * 4 + 4; ++s) {
-        float a[Cfg::TM], b[Cfg::TN];
+  for (int j = 0; j < Cfg::TN; ++j) b[0][j] = bp[32 * j];
 #pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i) a[i] = ap[2 * s * Cfg::LDA + 32 * i];
+  for (int s = 0; s < NS; ++s) {
+    const int cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < NS) {
 #pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) b[j] = bp[2 * s * Cfg::LDB + 32 * j];
+      for (int i = 0; i < Cfg::TM; ++i) a[nxt][i] = ap[2 * (s + 1) * Cfg::LDA + 32 * i];
 #pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-          for (int j = 0; j < Cfg::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
+      for (int j = 0; j < Cfg::TN; ++j) b[nxt][j] = bp[2 * (s + 1) * Cfg::LDB + 32 * j];
     }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
   }
 }
 
 template <class Cfg, class AL, class BL>
-__device__ __forceinline__ void gemm_mainloop(const AL& al, const BL& bl,
-                                              f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
+__device__ __forceinline__ void stage_store(const AL& al, const BL& bl, const typename AL::Raw& rawA,
+                                            const typename BL::Raw& rawB, float* As, float* Bs, int tid) {
+  float4 ra[Cfg::NVA], rb[Cfg::NVB];
+  al.finish(rawA, ra);
+  bl.finish(rawB, rb);
+  if (AL::kTypeR) lds_store_R<Cfg::LDA, Cfg::NVA>(As, ra, tid); else lds_store_C<Cfg::LDA, Cfg::NVA>(As, ra, tid);
+  if (BL::kTypeR) lds_store_R<Cfg::LDB, Cfg::NVB>(Bs, rb, tid); else lds_store_C<Cfg::LDB, Cfg::NVB>(Bs, rb, tid);
+}
+
+// K-steps [ks0, ks1) of the contraction; Ktot = logical K (for the short last step).
+template <class Cfg, class AL, class BL>
+__device__ __forceinline__ void gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
                                               int Ktot, float* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   float* const As0 = smem;
   float* const Bs0 = smem + 2 * BK * Cfg::LDA;
-  float4 ra[Cfg::NVA], rb[Cfg::NVB];
+  typename AL::Raw rawA;
+  typename BL::Raw rawB;
   if (ks0 >= ks1) return;
-  al.load(ks0, ra);
-  bl.load(ks0, rb);
-  if (AL::kTypeR) lds_store_R<Cfg::LDA, Cfg::NVA>(As0, ra, tid); else lds_store_C<Cfg::LDA, Cfg::NVA>(As0, ra, tid);
-  if (BL::kTypeR) lds_store_R<Cfg::LDB, Cfg::NVB>(Bs0, rb, tid); else lds_store_C<Cfg::LDB, Cfg::NVB>(Bs0, rb, tid);
+  al.issue(ks0, rawA);
+  bl.issue(ks0, rawB);
+  stage_store<Cfg>(al, bl, rawA, rawB, As0, Bs0, tid);
   __syncthreads();
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;
     const bool more = ks + 1 < ks1;
-    if (more) { al.load(ks + 1, ra); bl.load(ks + 1, rb); }
-    int kvalid = Ktot - ks * BK;
-    kvalid = kvalid > BK ? BK : kvalid;
     float* const Ac = As0 + cur * (BK * Cfg::LDA);
     float* const Bc = Bs0 + cur * (BK * Cfg::LDB);
-    float* const An = As0 + (cur ^ 1) * (BK * Cfg::LDA);
-    float* const Bn = Bs0 + (cur ^ 1) * (BK * Cfg::LDB);
-    mma_kstep<Cfg>(Ac, Bc, acc, wm, wn, lane, kvalid);
-    if (more) {
-      if (AL::kTypeR) lds_store_R<Cfg::LDA, Cfg::NVA>(An, ra, tid); else lds_store_C<Cfg::LDA, Cfg::NVA>(An, ra, tid);
-      if (BL::kTypeR) lds_store_R<Cfg::LDB, Cfg::NVB>(Bn, rb, tid); else lds_store_C<Cfg::LDB, Cfg::NVB>(Bn, rb, tid);
-    }
+    if (more) { al.issue(ks + 1, rawA); bl.issue(ks + 1, rawB); }
+    __builtin_amdgcn_sched_barrier(0);        // keep the loads above, their first use below the MFMAs
+    if (Ktot - ks * BK <= 8) mma_steps<Cfg, 4>(Ac, Bc, acc, wm, wn, lane);   // short tail (e.g. conv0: K = 36)
+    else mma_steps<Cfg, BK / 2>(Ac, Bc, acc, wm, wn, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stage_store<Cfg>(al, bl, rawA, rawB, As0 + (cur ^ 1) * (BK * Cfg::LDA), Bs0 + (cur ^ 1) * (BK * Cfg::LDB), tid);
     __syncthreads();
   }
 }
@@ -204,12 +233,18 @@ __device__ __forceinline__ int acc_col(int wn, int j, int lane) {
   return wn * Cfg::WN + 32 * j + (lane & 31);
 }
 
-// Tile id -> (mt, nt, split).  nt runs fastest so workgroups that share an A panel are neighbours,
-// and xcd_swizzle keeps neighbours on one XCD (shared L2).
-struct TileCoord { int mt, nt; };
-__device__ __forceinline__ TileCoord tile_coord(int tiles_n) {
+// Workgroup id -> (mt, nt, split).  The grid is one-dimensional; logical ids run nt fastest, then
+// mt, then split, and xcd_swizzle gives each XCD a contiguous range of logical ids: workgroups that
+// share an A panel (same mt) or the same reduction slice (same split) meet in one XCD's L2.
+struct TileCoord { int mt, nt, split; };
+__device__ __forceinline__ TileCoord tile_coord(int tiles_m, int tiles_n) {
   const int t = xcd_swizzle(blockIdx.x, gridDim.x);
-  TileCoord c; c.mt = t / tiles_n; c.nt = t - c.mt * tiles_n;
+  const int tiles = tiles_m * tiles_n;
+  TileCoord c;
+  c.split = t / tiles;
+  const int u = t - c.split * tiles;
+  c.mt = u / tiles_n;
+  c.nt = u - c.mt * tiles_n;
   return c;
 }
 

@@ -75,7 +75,10 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
   p.tiles_n = (g.Co + bm - 1) / bm;
   p.nk = (p.Mtot + BK - 1) / BK;
   const int tiles = p.tiles_m * p.tiles_n;
-  int splits = (512 + tiles - 1) / tiles;
+  // 2 workgroups fit a CU (LDS): tiles * splits must not exceed the 512 resident slots, or the few
+  // workgroups left over run alone in a second round and double the kernel's time.
+  int splits = 512 / tiles;
+  if (splits < 1) splits = 1;
   const int max_splits = p.nk / 8 > 1 ? p.nk / 8 : 1;
   if (splits > max_splits) splits = max_splits;
   p.ks_per_split = (p.nk + splits - 1) / splits;

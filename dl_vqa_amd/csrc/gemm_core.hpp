@@ -149,25 +149,40 @@ __device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x
   const int l31 = lane & 31, h = lane >> 5;
   const float* ap = As + h * Cfg::LDA + wm * Cfg::WM + l31;
   const float* bp = Bs + h * Cfg::LDB + wn * Cfg::WN + l31;
-  float a[2][Cfg::TM], b[2][Cfg::TN];
+  // Fragments are fetched a GROUP of 4 k2-steps ahead: the reads of group g+1 are issued, then a
+  // scheduling barrier, then the 4*TM*TN MFMAs of group g (>= 256 MFMA cycles), so LDS latency never
+  // sits between two MFMAs (left alone, hipcc sinks each read next to its consumer).
+  constexpr int GS = 4, NG = NS / GS;
+  static_assert(NS % GS == 0, "k2-steps come in groups of 4");
+  float a[2][GS][Cfg::TM], b[2][GS][Cfg::TN];
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i) a[0][i] = ap[32 * i];
+  for (int s = 0; s < GS; ++s) {
 #pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) b[0][j] = bp[32 * j];
+    for (int i = 0; i < Cfg::TM; ++i) a[0][s][i] = ap[2 * s * Cfg::LDA + 32 * i];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int cur = s & 1, nxt = cur ^ 1;
-    if (s + 1 < NS) {
+    for (int j = 0; j < Cfg::TN; ++j) b[0][s][j] = bp[2 * s * Cfg::LDB + 32 * j];
+  }
 #pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) a[nxt][i] = ap[2 * (s + 1) * Cfg::LDA + 32 * i];
+  for (int g = 0; g < NG; ++g) {
+    const int cur = g & 1, nxt = cur ^ 1;
+    if (g + 1 < NG) {
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) b[nxt][j] = bp[2 * (s + 1) * Cfg::LDB + 32 * j];
+      for (int s = 0; s < GS; ++s) {
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) a[nxt][s][i] = ap[2 * ((g + 1) * GS + s) * Cfg::LDA + 32 * i];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) b[nxt][s][j] = bp[2 * ((g + 1) * GS + s) * Cfg::LDB + 32 * j];
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+    for (int s = 0; s < GS; ++s)
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][s][i], b[cur][s][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -182,7 +197,7 @@ __device__ __forceinline__ void stage_store(const AL& al, const BL& bl, const ty
 }
 
 // K-steps [ks0, ks1) of the contraction; Ktot = logical K (for the short last step).
-template <class Cfg, class AL, class BL>
+template <class Cfg, class AL, class BL, bool SHORT_TAIL = false>
 __device__ __forceinline__ void gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
                                               int Ktot, float* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -203,7 +218,9 @@ __device__ __forceinline__ void gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg:
     float* const Bc = Bs0 + cur * (BK * Cfg::LDB);
     if (more) { al.issue(ks + 1, rawA); bl.issue(ks + 1, rawB); }
     __builtin_amdgcn_sched_barrier(0);        // keep the loads above, their first use below the MFMAs
-    if (Ktot - ks * BK <= 8) mma_steps<Cfg, 4>(Ac, Bc, acc, wm, wn, lane);   // short tail (e.g. conv0: K = 36)
+    // SHORT_TAIL (conv0 forward: K = 36 = 32 + 4): the last K-step runs 4 k2-steps instead of 16.  Kept out
+    // of the other kernels: two code paths make hipcc shuffle the accumulators between AGPRs and VGPRs.
+    if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, 4>(Ac, Bc, acc, wm, wn, lane);
     else mma_steps<Cfg, BK / 2>(Ac, Bc, acc, wm, wn, lane);
     __builtin_amdgcn_sched_barrier(0);
     if (more) stage_store<Cfg>(al, bl, rawA, rawB, As0 + (cur ^ 1) * (BK * Cfg::LDA), Bs0 + (cur ^ 1) * (BK * Cfg::LDB), tid);

@@ -44,6 +44,9 @@ struct TileCfg {
   static constexpr int NVA = BM / 32, NVB = BN / 32;  // float4 per thread per K-step
   static constexpr int SMEM_FLOATS = 2 * BK * (LDA + LDB);
   static constexpr int SMEM_BYTES = SMEM_FLOATS * 4;
+  // waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
+  // two 512-thread workgroups per CU (4 waves/SIMD, <= 128 VGPRs) up to 128x128, one above that
+  static constexpr int MIN_WAVES = (BM * BN > 128 * 128) ? 2 : 4;
 };
 
 // Thread -> staging coordinates, common to both loader types.
@@ -142,16 +145,28 @@ struct PlainC {
 };
 
 // ---------------------------------------------------------------- the main loop
-// NS k2-steps (2 k each) from one LDS image; fragment reads run one step ahead of the MFMAs.
+// Wave-specialised: a workgroup is 512 threads = 4 MFMA waves + 4 loader waves (one of each per SIMD).
+//   MFMA waves   : per K-step, 16 k2-steps of ds_read_b32 fragment reads + TM*TN MFMAs each; nothing else.
+//   loader waves : per K-step, finish() + ds_write the tile of step k+1 (loaded during step k-1) into the
+//                  other LDS buffer, then issue() the global loads of step k+2 into registers.
+//   one __syncthreads() per K-step joins the two roles.
+// Why: on gfx950 a wave issues in order, so every global_load / ds_write / address instruction a wave
+// executes is a hole in ITS MFMA stream (tools/mfma_peak.hip: 8 global_load_dwordx4 per K-step cost a
+// 4-wave workgroup 14-20 % of the MFMA rate even when they hit L2).  With the staging work on other
+// waves of the same SIMD, the MFMA waves sustain the bare ds_read + MFMA + barrier loop (96-98 % of
+// peak in the same micro-benchmark).  A global load has a full K-step (>= 4096 MFMA cycles) to land.
+// The two roles are separate loops (not one loop with a role test) so that each gets its own register
+// allocation: accumulators + fragments for one, Raw tiles + addresses for the other, both <= 128 VGPRs.
+constexpr int kThreads = 512;
+constexpr int kLoaderThreads = 256;
+
+// NS k2-steps from one LDS image; fragments are fetched a group of 4 k2-steps ahead of their MFMAs.
 template <class Cfg, int NS>
 __device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x16 (&acc)[Cfg::TM][Cfg::TN],
                                           int wm, int wn, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
   const float* ap = As + h * Cfg::LDA + wm * Cfg::WM + l31;
   const float* bp = Bs + h * Cfg::LDB + wn * Cfg::WN + l31;
-  // Fragments are fetched a GROUP of 4 k2-steps ahead: the reads of group g+1 are issued, then a
-  // scheduling barrier, then the 4*TM*TN MFMAs of group g (>= 256 MFMA cycles), so LDS latency never
-  // sits between two MFMAs (left alone, hipcc sinks each read next to its consumer).
   constexpr int GS = 4, NG = NS / GS;
   static_assert(NS % GS == 0, "k2-steps come in groups of 4");
   float a[2][GS][Cfg::TM], b[2][GS][Cfg::TN];
@@ -174,7 +189,7 @@ __device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x
         for (int j = 0; j < Cfg::TN; ++j) b[nxt][s][j] = bp[2 * ((g + 1) * GS + s) * Cfg::LDB + 32 * j];
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);   // reads of group g+1 stay above the MFMAs of group g
 #pragma unroll
     for (int s = 0; s < GS; ++s)
 #pragma unroll
@@ -186,46 +201,75 @@ __device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x
   }
 }
 
-template <class Cfg, class AL, class BL>
-__device__ __forceinline__ void stage_store(const AL& al, const BL& bl, const typename AL::Raw& rawA,
-                                            const typename BL::Raw& rawB, float* As, float* Bs, int tid) {
-  float4 ra[Cfg::NVA], rb[Cfg::NVB];
-  al.finish(rawA, ra);
-  bl.finish(rawB, rb);
-  if (AL::kTypeR) lds_store_R<Cfg::LDA, Cfg::NVA>(As, ra, tid); else lds_store_C<Cfg::LDA, Cfg::NVA>(As, ra, tid);
-  if (BL::kTypeR) lds_store_R<Cfg::LDB, Cfg::NVB>(Bs, rb, tid); else lds_store_C<Cfg::LDB, Cfg::NVB>(Bs, rb, tid);
+template <class Cfg, class L, bool IS_A>
+__device__ __forceinline__ void stage_store_one(const L& ld, const typename L::Raw& raw, float* dst, int ltid) {
+  constexpr int NV = IS_A ? Cfg::NVA : Cfg::NVB;
+  constexpr int LD = IS_A ? Cfg::LDA : Cfg::LDB;
+  float4 r[NV];
+  ld.finish(raw, r);
+  if (L::kTypeR) lds_store_R<LD, NV>(dst, r, ltid); else lds_store_C<LD, NV>(dst, r, ltid);
 }
 
-// K-steps [ks0, ks1) of the contraction; Ktot = logical K (for the short last step).
-template <class Cfg, class AL, class BL, bool SHORT_TAIL = false>
-__device__ __forceinline__ void gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
-                                              int Ktot, float* smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+__device__ __forceinline__ bool is_loader_wave() { return threadIdx.x >= kLoaderThreads; }
+// staging thread id of a loader thread (0..255); loaders are waves 4..7
+__device__ __forceinline__ int loader_tid() { return threadIdx.x - kLoaderThreads; }
+
+// Loader role: K-steps [ks0, ks1).  Loaders tolerate issue() past the end (addresses clamped, data masked).
+template <class Cfg, class AL, class BL>
+__device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, float* smem) {
+  const int ltid = loader_tid();
   float* const As0 = smem;
   float* const Bs0 = smem + 2 * BK * Cfg::LDA;
   typename AL::Raw rawA;
   typename BL::Raw rawB;
-  if (ks0 >= ks1) return;
   al.issue(ks0, rawA);
   bl.issue(ks0, rawB);
-  stage_store<Cfg>(al, bl, rawA, rawB, As0, Bs0, tid);
+  stage_store_one<Cfg, AL, true>(al, rawA, As0, ltid);
+  stage_store_one<Cfg, BL, false>(bl, rawB, Bs0, ltid);
+  al.issue(ks0 + 1, rawA);
+  bl.issue(ks0 + 1, rawB);
+  __syncthreads();
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int nxt = ((ks - ks0) & 1) ^ 1;
+    stage_store_one<Cfg, AL, true>(al, rawA, As0 + nxt * (BK * Cfg::LDA), ltid);
+    al.issue(ks + 2, rawA);
+    stage_store_one<Cfg, BL, false>(bl, rawB, Bs0 + nxt * (BK * Cfg::LDB), ltid);
+    bl.issue(ks + 2, rawB);
+    __syncthreads();
+  }
+}
+
+// MFMA role.  SHORT_TAIL (conv0 forward, K = 36 = 32 + 4): the last K-step runs 4 k2-steps instead of 16.
+template <class Cfg, bool SHORT_TAIL>
+__device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1, int Ktot,
+                                          const float* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const float* const As0 = smem;
+  const float* const Bs0 = smem + 2 * BK * Cfg::LDA;
   __syncthreads();
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;
-    const bool more = ks + 1 < ks1;
-    float* const Ac = As0 + cur * (BK * Cfg::LDA);
-    float* const Bc = Bs0 + cur * (BK * Cfg::LDB);
-    if (more) { al.issue(ks + 1, rawA); bl.issue(ks + 1, rawB); }
-    __builtin_amdgcn_sched_barrier(0);        // keep the loads above, their first use below the MFMAs
-    // SHORT_TAIL (conv0 forward: K = 36 = 32 + 4): the last K-step runs 4 k2-steps instead of 16.  Kept out
-    // of the other kernels: two code paths make hipcc shuffle the accumulators between AGPRs and VGPRs.
+    const float* const Ac = As0 + cur * (BK * Cfg::LDA);
+    const float* const Bc = Bs0 + cur * (BK * Cfg::LDB);
     if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, 4>(Ac, Bc, acc, wm, wn, lane);
     else mma_steps<Cfg, BK / 2>(Ac, Bc, acc, wm, wn, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) stage_store<Cfg>(al, bl, rawA, rawB, As0 + (cur ^ 1) * (BK * Cfg::LDA), Bs0 + (cur ^ 1) * (BK * Cfg::LDB), tid);
     __syncthreads();
   }
+}
+
+// Whole contraction over K-steps [ks0, ks1) (ks1 > ks0).  Returns true for MFMA waves (which hold the
+// accumulators and run the epilogue); loader waves return false and must do nothing further that
+// needs a barrier.
+template <class Cfg, class AL, class BL, bool SHORT_TAIL = false>
+__device__ __forceinline__ bool gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
+                                              int Ktot, float* smem) {
+  if (is_loader_wave()) {
+    loader_loop<Cfg>(al, bl, ks0, ks1, smem);
+    return false;
+  }
+  mfma_loop<Cfg, SHORT_TAIL>(acc, ks0, ks1, Ktot, smem);
+  return true;
 }
 
 template <class Cfg>

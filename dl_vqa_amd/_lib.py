@@ -31,6 +31,10 @@ PROTOTYPES = {
     "vqa_conv3x3_wgrad_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "vqa_conv3x3_wgrad": (i32, [f32p, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32,
                                 f32p, i64, i32, vp]),
+    "vqa_conv0_supported": (i32, [i32, i32, i32, i32, i32]),
+    "vqa_conv0_relu_pool_fwd": (i32, [f32p, f32p, f32p, f32p, u8p, i32, i32, i32, i32, i32, vp]),
+    "vqa_conv0_wgrad_workspace_bytes": (i64, [i32]),
+    "vqa_conv0_wgrad": (i32, [f32p, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, vp]),
     "vqa_dropout": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp]),
     "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, f32, u64, vp]),

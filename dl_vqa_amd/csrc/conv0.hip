@@ -1,0 +1,280 @@
+// First conv block (Cin <= 3, stride 1) — dedicated kernels.
+//
+// Reference: models/model.py:80-82, first iteration (Conv2d(3, 64, k=3) + ReLU + MaxPool2d(2,2)).
+//
+// Why not the generic implicit GEMM (conv.hip): K = 9*Cin = 27 is tiny, so a 128 x 64 x 32 tile spends its
+// time staging operands and pads K to 64 (2.4x the MFMA work); the layer is 4 % of the FLOPs but was
+// 9 % of the step.  Here
+//   forward : the input patch (6 image rows x all columns, PLANAR = the caller's NCHW, so no NHWC
+//             conversion pass at all) sits in LDS, the 27 x Co weights sit in REGISTERS as MFMA B
+//             fragments for the whole workgroup, and a wave streams 32-pixel M-tiles (8 pool windows):
+//             14 ds_read_b32 + 28 MFMA per tile, then the same in-register bias/ReLU/pool/arg-max epilogue.
+//   wgrad   : persistent workgroups walk pool-window rows; A = the 27 taps of a pixel read from the planar
+//             LDS patch (lane = tap), B = dY routed from the pooled gradient (staged in LDS with 16-byte
+//             loads); each wave keeps its 32 x Co partial dW in accumulators for its whole lifetime and
+//             writes ONE slab at the end (deterministic two-level reduction, no atomics).
+// LDS row strides are chosen per kernel so that the 32 lanes of a fragment read hit 32 different banks.
+#include "gemm_core.hpp"
+
+namespace vqa {
+
+constexpr int C0_MAX_NS = 18;   // k2-steps for Cin = 4
+
+__host__ __device__ inline int c0_round_stride(int W, int want_mod) {
+  int rs = W + 2;
+  while (rs % 32 != want_mod) ++rs;
+  return rs;
+}
+
+// ------------------------------------------------------------------ forward
+// grid (ceil(Hp/2), B); 256 threads; dynamic LDS = CI * 6 * RS floats (RS % 32 == 16)
+template <int CI, int TN>
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* pooled, uint8_t* amax,
+                                                        int H, int W, int Hp, int Wp, int RS) {
+  extern __shared__ __attribute__((aligned(16))) float patch[];
+  constexpr int K = 9 * CI, NS = (K + 1) / 2, Co = 32 * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y, py0 = 2 * blockIdx.x;
+  const int nwr = min(2, Hp - py0);
+  const int y0 = 2 * py0, nrows = 2 * nwr + 2;
+  const int plane = 6 * RS;
+  // stage the planar patch: rows y0 .. y0+nrows-1 of every input channel
+  for (int e = tid; e < CI * 6 * (W / 4); e += 256) {
+    const int c4 = e % (W / 4);
+    const int r = (e / (W / 4)) % 6;
+    const int c = e / (W / 4) / 6;
+    float4 v = f4zero();
+    if (r < nrows) v = *reinterpret_cast<const float4*>(x + ((int64_t)(b * CI + c) * H + y0 + r) * W + 4 * c4);
+    float* d = patch + c * plane + r * RS + 4 * c4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  // weights as B fragments, tap offsets as per-lane constants
+  float bf[NS][TN];
+  int koff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int k = 2 * s + h;
+    const bool kok = k < K;
+    const int kk = kok ? k : 0;
+    const int c = kk / 9, t = kk - 9 * c, ky = t / 3, kx = t - 3 * ky;
+    koff[s] = c * plane + ky * RS + kx;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[s][j] = kok ? w[(int64_t)(32 * j + l31) * K + kk] : 0.f;
+  }
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[j] = bias[32 * j + l31];
+  __syncthreads();
+
+  const int nwin = nwr * Wp, ntiles = (nwin + 7) / 8;
+  for (int t = wave; t < ntiles; t += 4) {
+    // A rows: row i = 4*window + pixel (the engine's window-in-4-registers layout)
+    int wdx = 8 * t + (l31 >> 2);
+    if (wdx >= nwin) wdx = 0;
+    const int wr = wdx / Wp, px = wdx - wr * Wp, j4 = l31 & 3;
+    const float* ap = patch + (2 * wr + (j4 >> 1)) * RS + 2 * px + (j4 & 1);
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float a = ap[koff[s]];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s][j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int wo = 8 * t + 2 * g + h;
+      if (wo < nwin) {
+        const int wr2 = wo / Wp, px2 = wo - wr2 * Wp;
+        const int64_t o = ((int64_t)(b * Hp + py0 + wr2) * Wp + px2) * Co + l31;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float best = acc[j][4 * g];
+          int a = 0;
+          if (acc[j][4 * g + 1] > best) { best = acc[j][4 * g + 1]; a = 1; }
+          if (acc[j][4 * g + 2] > best) { best = acc[j][4 * g + 2]; a = 2; }
+          if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
+          best += bv[j];
+          pooled[o + 32 * j] = best > 0.f ? best : 0.f;
+          amax[o + 32 * j] = best > 0.f ? (uint8_t)a : (uint8_t)4;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+// persistent grid; 256 threads; LDS = CI*PLANE (x patch, 4 rows) + Wp*Co (dP row) floats + Wp*Co bytes (arg-max row)
+template <int CI, int TN>
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+                                                          const uint8_t* __restrict__ am, float* slab, float* bias_slab,
+                                                          int B, int H, int W, int Hp, int Wp, int RS, int PLANE) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int K = 9 * CI, Co = 32 * TN;
+  float* patch = lds;
+  float* dps = lds + ((CI * PLANE + 3) & ~3);
+  uint8_t* ams = reinterpret_cast<uint8_t*>(dps + Wp * Co);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  // lane l31 owns tap i = l31 of the 32-row A operand (rows >= K are don't-care: never written out)
+  const int i = l31 < K ? l31 : 0;
+  const int c = i / 9, t9 = i - 9 * c, ky = t9 / 3, kx = t9 - 3 * ky;
+  const float* ap = patch + c * PLANE + ky * RS + kx + h;   // + h: the pixel pair (dx = h) of one MFMA
+  f32x16 acc[TN];
+  float bsum[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bsum[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+  const int rows_total = B * Hp;
+  const int rowv = Wp * Co;   // floats in one pooled-gradient row
+  for (int row = blockIdx.x; row < rows_total; row += gridDim.x) {
+    const int b = row / Hp, py = row - b * Hp;
+    __syncthreads();   // previous row fully consumed
+    for (int e = tid; e < CI * 4 * (W / 4); e += 256) {
+      const int c4 = e % (W / 4);
+      const int r = (e / (W / 4)) & 3;
+      const int cc = e / (W / 4) / 4;
+      const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(b * CI + cc) * H + 2 * py + r) * W + 4 * c4);
+      float* d = patch + cc * PLANE + r * RS + 4 * c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    const float* dprow = dp + (int64_t)row * rowv;
+    const uint8_t* amrow = am + (int64_t)row * rowv;
+    for (int e = tid; e < rowv / 4; e += 256) {
+      reinterpret_cast<float4*>(dps)[e] = reinterpret_cast<const float4*>(dprow)[e];
+      reinterpret_cast<uint32_t*>(ams)[e] = reinterpret_cast<const uint32_t*>(amrow)[e];
+    }
+    __syncthreads();
+    for (int px = wave; px < Wp; px += 4) {
+      float d[TN];
+      int id[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { d[j] = dps[px * Co + 32 * j + l31]; id[j] = ams[px * Co + 32 * j + l31]; }
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {          // pixel pair (dy = hs, dx = h)
+        const float a = ap[hs * RS + 2 * px];
+        const int jj = 2 * hs + h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float bvv = id[j] == jj ? d[j] : 0.f;
+          bsum[j] += bvv;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int part = blockIdx.x * 4 + wave;
+  float* out = slab + (int64_t)part * 32 * Co;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[k * Co + 32 * j + l31] = acc[j][r];
+    }
+    const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+    if (h == 0) bias_slab[(int64_t)part * Co + 32 * j + l31] = s;
+  }
+}
+
+// slab[parts][32][Co] -> dw[co][k]; bias_slab[parts][Co] -> dbias[co].  grid = K + 1 blocks of 256 threads.
+__global__ void conv0_wgrad_reduce_kernel(const float* slab, const float* bias_slab, float* dw, float* dbias,
+                                          int parts, int K, int Co) {
+  __shared__ float red[256];
+  const int k = blockIdx.x;          // k == K: the bias row
+  const int co = threadIdx.x % Co, sl = threadIdx.x / Co, nsl = 256 / Co;
+  float v = 0.f;
+  if (sl < nsl)
+    for (int p = sl; p < parts; p += nsl)
+      v += (k < K) ? slab[((int64_t)p * 32 + k) * Co + co] : bias_slab[(int64_t)p * Co + co];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (sl == 0) {
+    for (int s2 = 1; s2 < nsl; ++s2) v += red[s2 * Co + co];
+    if (k < K) dw[(int64_t)co * K + k] = v; else dbias[co] = v;
+  }
+}
+
+static bool c0_supported(int Ci, int H, int W, int Co, int stride) {
+  const int Hp = (H - 2) / 2, Wp = (W - 2) / 2;
+  // wgrad maps the 9*Ci taps onto the 32 rows of one MFMA A operand: Ci <= 3
+  if (!(Ci >= 1 && Ci <= 3 && stride == 1 && (Co == 32 || Co == 64) && W % 4 == 0 && H >= 6 && Hp > 0 && Wp > 0))
+    return false;
+  const size_t fwd = (size_t)Ci * 6 * c0_round_stride(W, 16) * 4;
+  const int rs = c0_round_stride(W, 11);
+  int plane = 4 * rs;
+  while (plane % 32 != 3) ++plane;
+  const size_t wg = ((size_t)Ci * plane + 4) * 4 + (size_t)Wp * Co * 5;
+  return fwd <= 60 * 1024 && wg <= 60 * 1024;
+}
+
+constexpr int kC0Blocks = 768;   // persistent wgrad grid: 3 workgroups per CU
+
+}  // namespace vqa
+
+using namespace vqa;
+
+#define C0_DISPATCH(CI, TN, ...)                                                          \
+  switch ((CI) * 10 + (TN)) {                                                             \
+    case 11: { constexpr int kCI = 1, kTN = 1; __VA_ARGS__; } break;                      \
+    case 12: { constexpr int kCI = 1, kTN = 2; __VA_ARGS__; } break;                      \
+    case 21: { constexpr int kCI = 2, kTN = 1; __VA_ARGS__; } break;                      \
+    case 22: { constexpr int kCI = 2, kTN = 2; __VA_ARGS__; } break;                      \
+    case 31: { constexpr int kCI = 3, kTN = 1; __VA_ARGS__; } break;                      \
+    case 32: { constexpr int kCI = 3, kTN = 2; __VA_ARGS__; } break;                      \
+    case 41: { constexpr int kCI = 4, kTN = 1; __VA_ARGS__; } break;                      \
+    case 42: { constexpr int kCI = 4, kTN = 2; __VA_ARGS__; } break;                      \
+    default: set_error("conv0: unsupported Ci=%d Co=%d", CI, 32 * (TN)); return VQA_ERR_INVALID; \
+  }
+
+extern "C" {
+
+int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride) { return c0_supported(Ci, H, W, Co, stride) ? 1 : 0; }
+
+int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, float* pooled, uint8_t* argmax,
+                            int B, int Ci, int H, int W, int Co, vqa_stream_t stream) {
+  VQA_REQUIRE(x_nchw && w && bias && pooled && argmax && B > 0, "vqa_conv0_relu_pool_fwd: bad args");
+  VQA_REQUIRE(c0_supported(Ci, H, W, Co, 1), "vqa_conv0_relu_pool_fwd: unsupported shape Ci=%d H=%d W=%d Co=%d", Ci, H, W, Co);
+  VQA_REQUIRE(((uintptr_t)x_nchw % 16) == 0, "vqa_conv0_relu_pool_fwd: input must be 16-byte aligned");
+  const int Hp = (H - 2) / 2, Wp = (W - 2) / 2, RS = c0_round_stride(W, 16);
+  const size_t lds = (size_t)Ci * 6 * RS * 4;
+  const dim3 grid((Hp + 1) / 2, B);
+  C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_fwd_kernel<kCI, kTN>), grid, dim3(256), lds, (hipStream_t)stream,
+                                              x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS));
+  return check_hip(hipGetLastError(), "conv0_fwd launch");
+}
+
+int64_t vqa_conv0_wgrad_workspace_bytes(int Co) { return (int64_t)kC0Blocks * 4 * (32 + 1) * Co * 4; }
+
+int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B,
+                    int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes, vqa_stream_t stream) {
+  VQA_REQUIRE(x_nchw && dpooled && argmax && dw && dbias && workspace, "vqa_conv0_wgrad: null pointer");
+  VQA_REQUIRE(c0_supported(Ci, H, W, Co, 1), "vqa_conv0_wgrad: unsupported shape Ci=%d H=%d W=%d Co=%d", Ci, H, W, Co);
+  if (workspace_bytes < vqa_conv0_wgrad_workspace_bytes(Co)) {
+    set_error("vqa_conv0_wgrad: workspace too small");
+    return VQA_ERR_WORKSPACE;
+  }
+  const int Hp = (H - 2) / 2, Wp = (W - 2) / 2, RS = c0_round_stride(W, 11);
+  int PLANE = 4 * RS;
+  while (PLANE % 32 != 3) ++PLANE;
+  const size_t lds = (((size_t)Ci * PLANE + 3) & ~(size_t)3) * 4 + (size_t)Wp * Co * 5;
+  int blocks = B * Hp < kC0Blocks ? B * Hp : kC0Blocks;
+  float* slab = workspace;
+  float* bias_slab = workspace + (int64_t)kC0Blocks * 4 * 32 * Co;
+  hipStream_t s = (hipStream_t)stream;
+  C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_wgrad_kernel<kCI, kTN>), dim3(blocks), dim3(256), lds, s, x_nchw,
+                                              dpooled, argmax, slab, bias_slab, B, H, W, Hp, Wp, RS, PLANE));
+  int rc = check_hip(hipGetLastError(), "conv0_wgrad launch");
+  if (rc) return rc;
+  hipLaunchKernelGGL(conv0_wgrad_reduce_kernel, dim3(9 * Ci + 1), dim3(256), 0, s, slab, bias_slab, dw, dbias,
+                     blocks * 4, 9 * Ci, Co);
+  return check_hip(hipGetLastError(), "conv0_wgrad_reduce launch");
+}
+
+}  // extern "C"

@@ -463,14 +463,21 @@ int colsum_launch(const float* x, int64_t ld, const uint8_t* mask, int64_t rows,
   return check_hip(hipGetLastError(), "colsum_stage2 launch");
 }
 
+// out[g] += sum over a slice of b (grid (G, slices)); out is zeroed by the launcher.  The result is the
+// x_conv bias gradient, which is ~0 by construction (softmax shift invariance), so the float atomics'
+// summation order is immaterial.
 __global__ void sum_bgp_kernel(const float* x, float* out, int B, int G, int P) {
   __shared__ float red[16];
   const int g = blockIdx.x;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   float s = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int i = threadIdx.x; i < P; i += blockDim.x) s += x[((int64_t)b * G + g) * P + i];
+  for (int b = b0; b < b1; ++b) {
+    const float* row = x + ((int64_t)b * G + g) * P;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) s += row[i];
+  }
   s = block_reduce(s, red, false);
-  if (threadIdx.x == 0) out[g] = s;
+  if (threadIdx.x == 0) atomicAdd(out + g, s);
 }
 
 // out[b][n] = sum_r part[(b*parts + r)*cols + n]
@@ -659,7 +666,9 @@ int vqa_colsum(const float* x, int64_t ld, const uint8_t* mask, int64_t rows, in
 
 int vqa_sum_bgp(const float* x, float* out, int B, int G, int P, vqa_stream_t stream) {
   VQA_REQUIRE(x && out, "vqa_sum_bgp: null pointer");
-  hipLaunchKernelGGL(sum_bgp_kernel, dim3(G), dim3(256), 0, STREAM, x, out, B, G, P);
+  int rc0 = check_hip(hipMemsetAsync(out, 0, (size_t)G * 4, STREAM), "sum_bgp memset");
+  if (rc0) return rc0;
+  hipLaunchKernelGGL(sum_bgp_kernel, dim3(G, B < 64 ? B : 64), dim3(256), 0, STREAM, x, out, B, G, P);
   return check_hip(hipGetLastError(), "sum_bgp launch");
 }
 

@@ -77,11 +77,20 @@ class Engine:
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
 
         # ---- image encoder: conv+relu+pool x L (models/model.py:79-84)
-        acts = [ops.nchw_to_nhwc4(v)]
+        # the first block has a dedicated kernel that reads the NCHW image as is (K = 27 is too thin for the
+        # generic implicit GEMM); otherwise the image is converted to NHWC4 once
+        fast0 = ops.conv0_supported(v.shape[1], v.shape[2], v.shape[3], self.channels[1], self.stride)
+        acts = [v if fast0 else ops.nchw_to_nhwc4(v)]
         idxs, wds = [], []
         for l in range(self.L):
             w = P[f"image.conv{l}.weight"]
             assert w.shape[0] == self.channels[l + 1]
+            if l == 0 and fast0:
+                pooled, am = ops.conv0_fwd(v, w, P["image.conv0.bias"])
+                acts.append(pooled)
+                idxs.append(am)
+                wds.append(None)
+                continue
             wf, wd = ops.conv_pack_weights(w, acts[-1].shape[3], need_wd=(keep and l > 0))
             pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l)
             acts.append(pooled)
@@ -151,7 +160,7 @@ class Engine:
             return logits, None
         ctx = SimpleNamespace(B=B, T=T, Pn=Pn, q=q, q_len=q_len, acts=acts, idxs=idxs, wds=wds, vn=vn, norm=norm,
                               x_emb=x_emb, lstm=lstm, v_in=v_in, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
-                              c_in=c_in, h1=h1, h1d=h1d, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
+                              c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
                               seed=seed, stages=dict(pooled=pooled, score=score, combined=combined))
         return logits, ctx
 
@@ -257,6 +266,9 @@ class Engine:
         # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first
         dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE)).view_as(ctx.acts[-1])
         for l in range(self.L - 1, -1, -1):
+            if l == 0 and ctx.fast0:
+                ops.conv0_wgrad(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])
+                continue
             ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
                            self.stride, tag=l)
             if l > 0:

@@ -95,6 +95,30 @@ def conv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: 
          ptr(ws), ws.numel() * 4, tag, stream())
 
 
+def conv0_supported(Ci: int, H: int, W: int, Co: int, stride: int) -> bool:
+    return bool(_lib.load().vqa_conv0_supported(Ci, H, W, Co, stride))
+
+
+def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
+    """First conv block straight from the NCHW image: (pooled NHWC [B,Hp,Wp,Co], argmax uint8)."""
+    B, Ci, H, W = x_nchw.shape
+    Co = w.shape[0]
+    Hp, Wp = conv_out_hw(H, W, 1)
+    pooled = torch.empty(B, Hp, Wp, Co, dtype=torch.float32, device=x_nchw.device)
+    amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x_nchw.device)
+    call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(pooled), ptr(amax), B, Ci, H, W, Co, stream())
+    return pooled, amax
+
+
+def conv0_wgrad(x_nchw, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor):
+    lib = _lib.load()
+    B, Ci, H, W = x_nchw.shape
+    Co = dw.shape[0]
+    ws = workspace(lib.vqa_conv0_wgrad_workspace_bytes(Co), x_nchw.device)
+    call("vqa_conv0_wgrad", ptr(x_nchw), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, Ci, H, W, Co, ptr(ws),
+         ws.numel() * 4, stream())
+
+
 def dropout(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     y = out if out is not None else torch.empty_like(x)
     call("vqa_dropout", ptr(x), ptr(y), x.numel(), p, seed, stream())

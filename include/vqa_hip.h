@@ -89,6 +89,17 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
                       float* dbias, int B, int H, int W, int CiP, int Ci, int Co, int stride,
                       float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
+/* First conv block, dedicated path (Cin <= 3, stride 1, Co in {32, 64}, W % 4 == 0): reads the caller's
+ * NCHW image directly (no layout conversion), weights/bias in torch layout, same pooled/argmax outputs
+ * as vqa_conv3x3_relu_pool_fwd.  vqa_conv0_supported() tells whether a shape takes this path. */
+int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride);
+int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, float* pooled,
+                            uint8_t* argmax, int B, int Ci, int H, int W, int Co, vqa_stream_t stream);
+int64_t vqa_conv0_wgrad_workspace_bytes(int Co);
+int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias,
+                    int B, int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes,
+                    vqa_stream_t stream);
+
 /* ---- dropout (nn.Dropout, 7 sites: models/model.py:84,156,185,186,194,201,204) ---------------
  * y = x * keep(seed, i) / (1-p); keep() is a counter-based hash, so backward calls the same
  * function on the gradient. In-place allowed. */

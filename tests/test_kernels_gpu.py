@@ -346,3 +346,35 @@ def test_dropout_statistics_and_determinism():
     vals = torch.unique(y1)
     assert len(vals) == 2 and abs(float(vals.max()) - 1 / 0.7) < 1e-6
     assert abs(float(y1.mean()) - 1.0) < 5e-3        # inverted dropout keeps the mean
+
+
+# ----------------------------------------------------------------------------- first conv block (dedicated path)
+@pytest.mark.parametrize("B,Ci,H,W,Co", [(2, 3, 20, 24, 32), (3, 3, 31, 28, 64), (2, 2, 16, 16, 64), (1, 1, 9, 12, 32),
+                                         (2, 3, 224, 224, 64)])
+def test_conv0_dedicated_fwd_wgrad(B, Ci, H, W, Co):
+    ops = _ops()
+    assert ops.conv0_supported(Ci, H, W, Co, 1)
+    assert not ops.conv0_supported(Ci, H, W, Co, 2) and not ops.conv0_supported(Ci, H, W + 1, Co, 1)
+    assert not ops.conv0_supported(4, H, W, Co, 1)
+    g = torch.Generator().manual_seed(B * 100 + H + Co)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)
+    b = torch.randn(Co, generator=g) * 0.1
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.max_pool2d(torch.relu(F.conv2d(x.double(), wr, br)), 2, 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xd = x.to(DEV)
+    pooled, amax = ops.conv0_fwd(xd, w.to(DEV), b.to(DEV))
+    dw, db = torch.empty(Co, Ci, 3, 3, device=DEV), torch.empty(Co, device=DEV)
+    ops.conv0_wgrad(xd, _nhwc(dy).to(DEV), amax, dw, db)
+    torch.cuda.synchronize()
+    check(f"conv0 fwd {B,Ci,H,W,Co}", pooled.permute(0, 3, 1, 2), yr, 1e-5)
+    assert bool(((pooled == 0) == (amax == 4)).all())
+    check("conv0 wgrad", dw, wr.grad, 3e-5)
+    check("conv0 bias grad", db, br.grad, 3e-5)
+    # same arg-max routing as the generic implicit-GEMM path
+    wf, _ = ops.conv_pack_weights(w.to(DEV), 4, need_wd=False)   # generic path: channels padded to 4
+    p2, a2 = ops.conv_fwd(ops.nchw_to_nhwc4(xd), wf, b.to(DEV), 1)
+    torch.cuda.synchronize()
+    assert float((p2 - pooled).abs().max()) < 1e-5 and float((a2 != amax).float().mean()) < 1e-3

@@ -50,7 +50,15 @@ def main():
     # conv layers of the reference architecture at 224x224
     H = 224
     chans = [3, 64, 128, 256]
-    x = ops.nchw_to_nhwc4(torch.randn(B, 3, H, H, device=dev))
+    img = torch.randn(B, 3, H, H, device=dev)
+    w0 = torch.randn(64, 3, 3, 3, device=dev) * 0.2
+    b0 = torch.zeros(64, device=dev)
+    f0 = 2.0 * B * 222 * 222 * 64 * 27
+    p0, a0 = ops.conv0_fwd(img, w0, b0)
+    run("conv0_fast_fwd", f0, lambda: ops.conv0_fwd(img, w0, b0))
+    dp0, dw0, db0 = torch.randn_like(p0), torch.empty_like(w0), torch.empty_like(b0)
+    run("conv0_fast_wgrad", f0, lambda: ops.conv0_wgrad(img, dp0, a0, dw0, db0))
+    x = ops.nchw_to_nhwc4(img)
     for l in range(3):
         Ci, Co = chans[l], chans[l + 1]
         CiP = x.shape[3]

@@ -169,18 +169,26 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
       }
     }
   }
-  const int part = blockIdx.x * 4 + wave;
-  float* out = slab + (int64_t)part * 32 * Co;
+  // combine the 4 waves of the workgroup through LDS, then ONE partial per workgroup
+  __syncthreads();
+  float* comb = lds;                               // [4][32][Co] floats, fits the staging area
+  float* cb = lds + 4 * 32 * Co;                   // [4][Co]
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
-      out[k * Co + 32 * j + l31] = acc[j][r];
+      comb[(wave * 32 + k) * Co + 32 * j + l31] = acc[j][r];
     }
     const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-    if (h == 0) bias_slab[(int64_t)part * Co + 32 * j + l31] = s;
+    if (h == 0) cb[wave * Co + 32 * j + l31] = s;
   }
+  __syncthreads();
+  float* out = slab + (int64_t)blockIdx.x * 32 * Co;
+  for (int e = tid; e < 32 * Co; e += 256)
+    out[e] = comb[e] + comb[32 * Co + e] + comb[2 * 32 * Co + e] + comb[3 * 32 * Co + e];
+  for (int e = tid; e < Co; e += 256)
+    bias_slab[(int64_t)blockIdx.x * Co + e] = cb[e] + cb[Co + e] + cb[2 * Co + e] + cb[3 * Co + e];
 }
 
 // slab[parts][32][Co] -> dw[co][k]; bias_slab[parts][Co] -> dbias[co].  grid = K + 1 blocks of 256 threads.
@@ -250,7 +258,7 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
   return check_hip(hipGetLastError(), "conv0_fwd launch");
 }
 
-int64_t vqa_conv0_wgrad_workspace_bytes(int Co) { return (int64_t)kC0Blocks * 4 * (32 + 1) * Co * 4; }
+int64_t vqa_conv0_wgrad_workspace_bytes(int Co) { return (int64_t)kC0Blocks * (32 + 1) * Co * 4; }
 
 int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B,
                     int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes, vqa_stream_t stream) {
@@ -263,17 +271,18 @@ int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* ar
   const int Hp = (H - 2) / 2, Wp = (W - 2) / 2, RS = c0_round_stride(W, 11);
   int PLANE = 4 * RS;
   while (PLANE % 32 != 3) ++PLANE;
-  const size_t lds = (((size_t)Ci * PLANE + 3) & ~(size_t)3) * 4 + (size_t)Wp * Co * 5;
+  size_t lds = (((size_t)Ci * PLANE + 3) & ~(size_t)3) * 4 + (size_t)Wp * Co * 5;
+  if (lds < (size_t)(4 * 32 + 4) * Co * 4) lds = (size_t)(4 * 32 + 4) * Co * 4;   // the end-of-kernel combine area
   int blocks = B * Hp < kC0Blocks ? B * Hp : kC0Blocks;
   float* slab = workspace;
-  float* bias_slab = workspace + (int64_t)kC0Blocks * 4 * 32 * Co;
+  float* bias_slab = workspace + (int64_t)kC0Blocks * 32 * Co;
   hipStream_t s = (hipStream_t)stream;
   C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_wgrad_kernel<kCI, kTN>), dim3(blocks), dim3(256), lds, s, x_nchw,
                                               dpooled, argmax, slab, bias_slab, B, H, W, Hp, Wp, RS, PLANE));
   int rc = check_hip(hipGetLastError(), "conv0_wgrad launch");
   if (rc) return rc;
   hipLaunchKernelGGL(conv0_wgrad_reduce_kernel, dim3(9 * Ci + 1), dim3(256), 0, s, slab, bias_slab, dw, dbias,
-                     blocks * 4, 9 * Ci, Co);
+                     blocks, 9 * Ci, Co);
   return check_hip(hipGetLastError(), "conv0_wgrad_reduce launch");
 }
 

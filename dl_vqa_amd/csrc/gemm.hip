@@ -124,7 +124,10 @@ static GemmPlan plan_gemm(int M, int N, int K) {
   if (t128 >= 200) p.big = 1;
   else if (t64 >= 200) p.big = 0;
   else {
-    p.big = (M >= 128 && N >= 128) ? 1 : 0;
+    // few big tiles + many splits = short K loops dominated by prologue/epilogue (LSTM dh GEMM, M = 256:
+    // 16 tiles x 24 splits of 6 K-steps ran at 21 % of peak): below 64 big tiles use 64x64 tiles, whose
+    // 4x larger tile count needs 4x fewer splits
+    p.big = (M >= 128 && N >= 128 && t128 >= 64) ? 1 : 0;
     const int tiles = p.big ? t128 : t64;
     const int max_splits = nk / 4 > 1 ? nk / 4 : 1;
     splits = (384 + tiles - 1) / tiles;

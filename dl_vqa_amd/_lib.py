@@ -23,7 +23,7 @@ PROTOTYPES = {
     "vqa_prof_read": (i32, [C.POINTER(i32), C.POINTER(f32)]),
     "vqa_gemm_workspace_bytes": (i64, [i32, i32, i32]),
     "vqa_gemm": (i32, [f32p, i64, i32, f32p, i64, i32, f32p, i64, i32, i32, i32, f32p, f32p,
-                       f32p, i64, i32, i32, i32, i32, f32p, i64, i32, vp]),
+                       f32p, i64, i32, i32, i32, i32, f32p, f32p, i64, i32, vp]),
     "vqa_nchw_to_nhwc4": (i32, [f32p, f32p, i32, i32, i32, i32, vp]),
     "vqa_conv_pack_weights": (i32, [f32p, f32p, f32p, i32, i32, i32, vp]),
     "vqa_conv3x3_relu_pool_fwd": (i32, [f32p, f32p, f32p, f32p, u8p, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -42,9 +42,9 @@ PROTOTYPES = {
     "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
     "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
     "vqa_lstm_cell_bwd": (i32, [f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, i32, i32, vp]),
-    "vqa_att_score_fwd": (i32, [f32p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
+    "vqa_att_score_fwd": (i32, [f32p, f32p, i32, f32p, f32p, i32, i32, i32, i32, f32, u64, f32p, vp]),
     "vqa_att_row_splits": (i32, [i32]),
-    "vqa_att_score_bwd": (i32, [f32p, f32p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
+    "vqa_att_score_bwd": (i32, [f32p, f32p, i32, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, i32, f32p, f32p, vp]),
     "vqa_att_apply_fwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, i32, i32, i32, vp]),
     "vqa_att_apply_bwd": (i32, [f32p, i64, f32p, f32p, f32p, f32p, i32, i32, i32, i32, vp]),
     "vqa_softce_fwd_bwd": (i32, [f32p, i64, i64p, i64p, i32, i32, i32, f32, f32p, f32p, f32p, i64, vp]),

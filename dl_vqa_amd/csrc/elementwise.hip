@@ -168,14 +168,21 @@ __global__ void lstm_cell_bwd_kernel(const float* gates, const float* c_in, cons
 }
 
 // ------------------------------------------------------------------ attention score (x_conv)
+// x = relu(v' (+|*) q') is xs [M][mid]; for do_option '|' x = relu(cat[v', tile(q')]) has 2*mid channels:
+// the v' half is xs, the q' half is relu(qcat[b][:]) replicated over positions (but with its own
+// per-position dropout mask, as nn.Dropout acts on the concatenated tensor).  xld = channels of x.
 template <int G>
-__global__ void att_score_fwd_kernel(const float* xs, const float* wx, const float* bx, float* score, int64_t M,
-                                     int P, int mid, float p, float inv_keep, uint64_t seed) {
+__global__ void att_score_fwd_kernel(const float* xs, const float* wx, int wx_ld, const float* bx, float* score,
+                                     int64_t M, int P, int mid, float p, float inv_keep, uint64_t seed,
+                                     const float* qcat) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int nch = mid >> 2;
+  const int xld = qcat ? 2 * mid : mid;
   for (int64_t m = wave; m < M; m += nwaves) {
+    const int64_t b = m / P;
+    const int pp = (int)(m - b * P);
     const float4* row = reinterpret_cast<const float4*>(xs + m * mid);
     float acc[G];
 #pragma unroll
@@ -183,18 +190,30 @@ __global__ void att_score_fwd_kernel(const float* xs, const float* wx, const flo
     for (int c = lane; c < nch; c += 64) {
       float4 x = row[c];
       if (p > 0.f) {
-        const uint64_t e = (uint64_t)m * mid + 4 * c;
+        const uint64_t e = (uint64_t)m * xld + 4 * c;
         x.x *= drop_scale(seed, e, p, inv_keep); x.y *= drop_scale(seed, e + 1, p, inv_keep);
         x.z *= drop_scale(seed, e + 2, p, inv_keep); x.w *= drop_scale(seed, e + 3, p, inv_keep);
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const float4 w = reinterpret_cast<const float4*>(wx + (int64_t)g * mid)[c];
+        const float4 w = reinterpret_cast<const float4*>(wx + (int64_t)g * wx_ld)[c];
         acc[g] += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
       }
+      if (qcat) {
+        float4 q = reinterpret_cast<const float4*>(qcat + b * mid)[c];
+        q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f);
+        if (p > 0.f) {
+          const uint64_t e = (uint64_t)m * xld + mid + 4 * c;
+          q.x *= drop_scale(seed, e, p, inv_keep); q.y *= drop_scale(seed, e + 1, p, inv_keep);
+          q.z *= drop_scale(seed, e + 2, p, inv_keep); q.w *= drop_scale(seed, e + 3, p, inv_keep);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 w = reinterpret_cast<const float4*>(wx + (int64_t)g * wx_ld + mid)[c];
+          acc[g] += q.x * w.x + q.y * w.y + q.z * w.z + q.w * w.w;
+        }
+      }
     }
-    const int64_t b = m / P;
-    const int pp = (int)(m - b * P);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const float v = wave_sum(acc[g]);
@@ -203,22 +222,33 @@ __global__ void att_score_fwd_kernel(const float* xs, const float* wx, const flo
   }
 }
 
-// grid (B, RS); thread -> float4 column chunks; loops rows of its split
+// grid (B, RS); thread -> float4 column chunks; loops the rows of its split.
+// mode 0 '+': xs <- dz = (x>0) * mask * sum_g ds*wx            dq' part = sum_p dz
+// mode 1 '*': xs <- dv' = dz * q'[b]                             dq' part = sum_p dz * v'
+// mode 2 '|': xs <- dv' = dz (v' half);  q' half: dq' part = (q'>0) * sum_p mask_q * sum_g ds*wx[g][mid+n]
+// dwx_part[part][G][xld]: sum_p ds[g] * dropout(x) over the rows of the part (both halves for '|').
 template <int G>
-__global__ void att_score_bwd_kernel(const float* dscore, const float* wx, float* xs, float* dwx_part,
-                                     float* dq_part, int P, int mid, int RS, float p, float inv_keep, uint64_t seed) {
+__global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int wx_ld, float* xs, float* dwx_part,
+                                     float* dq_part, int P, int mid, int RS, float p, float inv_keep, uint64_t seed,
+                                     int mode, const float* vprime, const float* qp) {
   const int b = blockIdx.x, rs = blockIdx.y;
   const int rows_per = (P + RS - 1) / RS;
   const int p0 = rs * rows_per, p1 = min(P, p0 + rows_per);
   const int nch = mid >> 2;
+  const int xld = mode == 2 ? 2 * mid : mid;
   const int64_t part = (int64_t)b * RS + rs;
   for (int c = threadIdx.x; c < nch; c += blockDim.x) {
-    float4 w[G], dw[G];
+    float4 w[G], dw[G], w2[G], dw2[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      w[g] = reinterpret_cast<const float4*>(wx + (int64_t)g * mid)[c];
+      w[g] = reinterpret_cast<const float4*>(wx + (int64_t)g * wx_ld)[c];
       dw[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dw2[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      w2[g] = mode == 2 ? reinterpret_cast<const float4*>(wx + (int64_t)g * wx_ld + mid)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode != 0) qv = reinterpret_cast<const float4*>(qp + (int64_t)b * mid)[c];
+    const float4 rq = make_float4(fmaxf(qv.x, 0.f), fmaxf(qv.y, 0.f), fmaxf(qv.z, 0.f), fmaxf(qv.w, 0.f));
     float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int pp = p0; pp < p1; ++pp) {
       const int64_t m = (int64_t)b * P + pp;
@@ -226,25 +256,50 @@ __global__ void att_score_bwd_kernel(const float* dscore, const float* wx, float
       const float4 x = *xp;
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
       if (p > 0.f) {
-        const uint64_t e = (uint64_t)m * mid + 4 * c;
+        const uint64_t e = (uint64_t)m * xld + 4 * c;
         sc.x = drop_scale(seed, e, p, inv_keep); sc.y = drop_scale(seed, e + 1, p, inv_keep);
         sc.z = drop_scale(seed, e + 2, p, inv_keep); sc.w = drop_scale(seed, e + 3, p, inv_keep);
       }
+      float ds[G];
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const float ds = dscore[((int64_t)b * G + g) * P + pp];
-        t.x += ds * w[g].x; t.y += ds * w[g].y; t.z += ds * w[g].z; t.w += ds * w[g].w;
-        dw[g].x += ds * x.x * sc.x; dw[g].y += ds * x.y * sc.y; dw[g].z += ds * x.z * sc.z; dw[g].w += ds * x.w * sc.w;
+        ds[g] = dscore[((int64_t)b * G + g) * P + pp];
+        t.x += ds[g] * w[g].x; t.y += ds[g] * w[g].y; t.z += ds[g] * w[g].z; t.w += ds[g] * w[g].w;
+        dw[g].x += ds[g] * x.x * sc.x; dw[g].y += ds[g] * x.y * sc.y; dw[g].z += ds[g] * x.z * sc.z; dw[g].w += ds[g] * x.w * sc.w;
       }
       float4 d;
       d.x = x.x > 0.f ? t.x * sc.x : 0.f; d.y = x.y > 0.f ? t.y * sc.y : 0.f;
       d.z = x.z > 0.f ? t.z * sc.z : 0.f; d.w = x.w > 0.f ? t.w * sc.w : 0.f;
+      if (mode == 0) {
+        dq.x += d.x; dq.y += d.y; dq.z += d.z; dq.w += d.w;
+      } else if (mode == 1) {
+        const float4 vp = reinterpret_cast<const float4*>(vprime + m * mid)[c];
+        dq.x += d.x * vp.x; dq.y += d.y * vp.y; dq.z += d.z * vp.z; dq.w += d.w * vp.w;
+        d.x *= qv.x; d.y *= qv.y; d.z *= qv.z; d.w *= qv.w;
+      } else {
+        float4 s2 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p > 0.f) {
+          const uint64_t e = (uint64_t)m * xld + mid + 4 * c;
+          s2.x = drop_scale(seed, e, p, inv_keep); s2.y = drop_scale(seed, e + 1, p, inv_keep);
+          s2.z = drop_scale(seed, e + 2, p, inv_keep); s2.w = drop_scale(seed, e + 3, p, inv_keep);
+        }
+        float4 t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          t2.x += ds[g] * w2[g].x; t2.y += ds[g] * w2[g].y; t2.z += ds[g] * w2[g].z; t2.w += ds[g] * w2[g].w;
+          dw2[g].x += ds[g] * rq.x * s2.x; dw2[g].y += ds[g] * rq.y * s2.y; dw2[g].z += ds[g] * rq.z * s2.z; dw2[g].w += ds[g] * rq.w * s2.w;
+        }
+        dq.x += qv.x > 0.f ? t2.x * s2.x : 0.f; dq.y += qv.y > 0.f ? t2.y * s2.y : 0.f;
+        dq.z += qv.z > 0.f ? t2.z * s2.z : 0.f; dq.w += qv.w > 0.f ? t2.w * s2.w : 0.f;
+      }
       *xp = d;
-      dq.x += d.x; dq.y += d.y; dq.z += d.z; dq.w += d.w;
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) reinterpret_cast<float4*>(dwx_part + (part * G + g) * mid)[c] = dw[g];
+    for (int g = 0; g < G; ++g) {
+      reinterpret_cast<float4*>(dwx_part + (part * G + g) * xld)[c] = dw[g];
+      if (mode == 2) reinterpret_cast<float4*>(dwx_part + (part * G + g) * xld + mid)[c] = dw2[g];
+    }
     reinterpret_cast<float4*>(dq_part + part * mid)[c] = dq;
   }
 }
@@ -600,12 +655,13 @@ int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out,
     default: set_error("glimpses=%d unsupported (1..4)", G); return VQA_ERR_INVALID; \
   }
 
-int vqa_att_score_fwd(const float* xs, const float* wx, const float* bx, float* score, int B, int P, int mid, int G,
-                      float p, uint64_t seed, vqa_stream_t stream) {
-  VQA_REQUIRE(xs && wx && bx && score && mid % 4 == 0, "vqa_att_score_fwd: bad args");
+int vqa_att_score_fwd(const float* xs, const float* wx, int wx_ld, const float* bx, float* score, int B, int P, int mid,
+                      int G, float p, uint64_t seed, const float* qcat, vqa_stream_t stream) {
+  VQA_REQUIRE(xs && wx && bx && score && mid % 4 == 0 && wx_ld % 4 == 0 && wx_ld >= (qcat ? 2 * mid : mid),
+              "vqa_att_score_fwd: bad args");
   const int64_t M = (int64_t)B * P;
-  DISPATCH_G(G, hipLaunchKernelGGL(att_score_fwd_kernel<kG>, dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx, bx,
-                                   score, M, P, mid, p, KEEP(p), seed));
+  DISPATCH_G(G, hipLaunchKernelGGL(att_score_fwd_kernel<kG>, dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx, wx_ld,
+                                   bx, score, M, P, mid, p, KEEP(p), seed, qcat));
   return check_hip(hipGetLastError(), "att_score_fwd launch");
 }
 
@@ -614,12 +670,17 @@ int vqa_att_row_splits(int P) {
   return rs < 1 ? 1 : (rs > 8 ? 8 : rs);
 }
 
-int vqa_att_score_bwd(const float* dscore, const float* wx, float* xs_inout, float* dwx_part, float* dq_part, int B,
-                      int P, int mid, int G, float p, uint64_t seed, vqa_stream_t stream) {
-  VQA_REQUIRE(dscore && wx && xs_inout && dwx_part && dq_part && mid % 4 == 0, "vqa_att_score_bwd: bad args");
+int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, float* xs_inout, float* dwx_part,
+                      float* dq_part, int B, int P, int mid, int G, float p, uint64_t seed, int mode,
+                      const float* vprime, const float* qp, vqa_stream_t stream) {
+  VQA_REQUIRE(dscore && wx && xs_inout && dwx_part && dq_part && mid % 4 == 0 && wx_ld % 4 == 0,
+              "vqa_att_score_bwd: bad args");
+  VQA_REQUIRE(mode >= 0 && mode <= 2 && (mode != 1 || (vprime && qp)) && (mode != 2 || qp) &&
+                  wx_ld >= (mode == 2 ? 2 * mid : mid),
+              "vqa_att_score_bwd: mode %d needs its operands (vprime/qp) and a matching wx_ld", mode);
   const int RS = vqa_att_row_splits(P);
-  DISPATCH_G(G, hipLaunchKernelGGL(att_score_bwd_kernel<kG>, dim3(B, RS), dim3(256), 0, STREAM, dscore, wx, xs_inout,
-                                   dwx_part, dq_part, P, mid, RS, p, KEEP(p), seed));
+  DISPATCH_G(G, hipLaunchKernelGGL(att_score_bwd_kernel<kG>, dim3(B, RS), dim3(256), 0, STREAM, dscore, wx, wx_ld,
+                                   xs_inout, dwx_part, dq_part, P, mid, RS, p, KEEP(p), seed, mode, vprime, qp));
   return check_hip(hipGetLastError(), "att_score_bwd launch");
 }
 

@@ -51,6 +51,7 @@ struct EpiParams {
   const float* bias1; const float* bias2;
   const float* rg; int64_t rg_ld; int rg_div; int rg_op;
   int relu; int accumulate;
+  float* aux;   // optional: raw product before the epilogue, same shape/ld as C
   float* slab;  // != nullptr: split-K partials [split][M][N]
 };
 
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(512, Cfg::MIN_WAVES) void gemm_kernel(typename AL::
         const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
         if (row < pe.M && col < pe.N) {
           if (slab) slab[(int64_t)row * pe.N + col] = acc[i][j][r];
-          else pe.C[(int64_t)row * pe.ldc + col] = epi_apply(pe, acc[i][j][r], row, col);
+          else {
+            if (pe.aux) pe.aux[(int64_t)row * pe.ldc + col] = acc[i][j][r];
+            pe.C[(int64_t)row * pe.ldc + col] = epi_apply(pe, acc[i][j][r], row, col);
+          }
         }
       }
     }
@@ -108,6 +112,7 @@ __global__ void splitk_reduce_kernel(EpiParams pe, int splits) {
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += pe.slab[(int64_t)s * total + e];
     const int row = (int)(e / pe.N), col = (int)(e - (int64_t)row * pe.N);
+    if (pe.aux) pe.aux[(int64_t)row * pe.ldc + col] = v;
     pe.C[(int64_t)row * pe.ldc + col] = epi_apply(pe, v, row, col);
   }
 }
@@ -223,7 +228,7 @@ int64_t vqa_gemm_workspace_bytes(int M, int N, int K) {
 int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
              int64_t ldc, int M, int N, int K, const float* bias1, const float* bias2,
              const float* rowgroup, int64_t rg_ld, int rg_div, int rg_op, int relu, int accumulate,
-             float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream) {
+             float* aux, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream) {
   VQA_REQUIRE(A && B && C, "vqa_gemm: null operand");
   VQA_REQUIRE(M > 0 && N > 0 && K > 0, "vqa_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   VQA_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && lda % 4 == 0 && ldb % 4 == 0,
@@ -232,7 +237,7 @@ int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ld
   VQA_REQUIRE(!rowgroup || rg_div > 0, "vqa_gemm: rg_div must be positive");
   hipStream_t s = (hipStream_t)stream;
   const GemmPlan p = plan_gemm(M, N, K);
-  EpiParams pe{C, ldc, M, N, bias1, bias2, rowgroup, rg_ld, rg_div, rg_op, relu, accumulate, nullptr};
+  EpiParams pe{C, ldc, M, N, bias1, bias2, rowgroup, rg_ld, rg_div, rg_op, relu, accumulate, aux, nullptr};
   if (p.splits > 1) {
     const int64_t need = (int64_t)p.splits * M * N * 4;
     if (!workspace || workspace_bytes < need) {

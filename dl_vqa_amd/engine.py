@@ -43,9 +43,9 @@ class Engine:
         self.mid = a["hidden_dim"]
         self.G = a["glimpses"]
         self.do_option = a["do_option"]
-        if self.do_option not in ("+",):
-            raise NotImplementedError(f"attention do_option {self.do_option!r}: only '+' (config.yaml:68) is "
-                                      "implemented on the HIP path so far")
+        if self.do_option not in ("+", "*", "|"):
+            raise ValueError(f"attention do_option {self.do_option!r} (the reference knows '+', '*', '|')")
+        self.att_mode = {"+": 0, "*": 1, "|": 2}[self.do_option]
         self.hid = c["hidden_dim"]
         self.A = cfg["max_answers"]
         self.p_text, self.p_image, self.p_att, self.p_cls = t["dropout"], i["dropout"], a["dropout"], c["dropout"]
@@ -139,11 +139,16 @@ class Engine:
             v_in, q_in, ld_q = vn, qf, Dc
         qp = new(B, mid)
         ops.gemm(q_in, P["attention.q_lin.weight"], qp, B, mid, Q, lda=ld_q, bias1=P["attention.q_lin.bias"], tag=20)
+        # x = relu(v' + q') | relu(v' * q') | relu(cat[v', q'])  (model.py:188-193); v' itself is only kept for
+        # '*' (its backward needs it), as the aux output of the same GEMM
         xs = new(B * Pn, mid)
-        ops.gemm(v_in, P["attention.v_conv.weight"], xs, B * Pn, mid, C, rowgroup=qp, rg_div=Pn, rg_op=0, relu=True,
-                 tag=21)
+        mode = self.att_mode
+        vprime = new(B * Pn, mid) if (mode == 1 and keep) else None
+        ops.gemm(v_in, P["attention.v_conv.weight"], xs, B * Pn, mid, C, rowgroup=(qp if mode != 2 else None),
+                 rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, aux=vprime, tag=21)
         wx = P["attention.x_conv.weight"]
-        score = ops.att_score_fwd(xs, wx.view(G, -1), P["attention.x_conv.bias"], B, Pn, p_att, sd(SITE_ATT_X))
+        score = ops.att_score_fwd(xs, wx.view(G, -1), P["attention.x_conv.bias"], B, Pn, p_att, sd(SITE_ATT_X),
+                                  qcat=(qp if mode == 2 else None))
         # ---- softmax over positions + weighted sum (model.py:208-221) -> combined[:, :G*C]
         probs = ops.att_apply_fwd(score, vn, combined, Dc)
 
@@ -160,7 +165,7 @@ class Engine:
             return logits, None
         ctx = SimpleNamespace(B=B, T=T, Pn=Pn, q=q, q_len=q_len, acts=acts, idxs=idxs, wds=wds, vn=vn, norm=norm,
                               x_emb=x_emb, lstm=lstm, v_in=v_in, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
-                              c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
+                              c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, vprime=vprime, qp=qp, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
                               seed=seed, stages=dict(pooled=pooled, score=score, combined=combined))
         return logits, ctx
 
@@ -206,9 +211,10 @@ class Engine:
         dscore, dvn = ops.att_apply_bwd(dcomb, Dc, ctx.probs, ctx.vn)
         ops.sum_bgp(dscore, Gr["attention.x_conv.bias"])
         wx = P["attention.x_conv.weight"].view(G, -1)
-        dwx_part, dq_part, RS = ops.att_score_bwd(dscore, wx, ctx.xs, B, Pn, ctx.p_att, sd(SITE_ATT_X))
-        dxpre = ctx.xs                                          # overwritten in place
-        ops.colsum(dwx_part, B * RS, G * mid, Gr["attention.x_conv.weight"])
+        dwx_part, dq_part, RS = ops.att_score_bwd(dscore, wx, ctx.xs, B, Pn, ctx.p_att, sd(SITE_ATT_X),
+                                                  mode=self.att_mode, vprime=ctx.vprime, qp=ctx.qp)
+        dxpre = ctx.xs                                          # overwritten in place: now d loss / d v'
+        ops.colsum(dwx_part, B * RS, wx.numel(), Gr["attention.x_conv.weight"])
         dqp = new(B, mid)
         ops.sum_parts(dq_part, dqp, B, RS, mid)
         ops.gemm(dxpre, ctx.v_in, Gr["attention.v_conv.weight"], mid, C, B * Pn, transA=True, transB=False, lda=mid,

@@ -31,7 +31,7 @@ def _chk(t: torch.Tensor, dtype=torch.float32):
 
 def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, *, transA=False,
          transB=True, lda=None, ldb=None, ldc=None, bias1=None, bias2=None, rowgroup=None, rg_div=1,
-         rg_op=0, relu=False, accumulate=False, tag=0) -> torch.Tensor:
+         rg_op=0, relu=False, accumulate=False, aux=None, tag=0) -> torch.Tensor:
     """C[M,N] = act(op(A) op(B) (op) rowgroup + bias) (+C).  Leading dims default to the stored row length."""
     lib = _lib.load()
     lda = lda if lda is not None else (M if transA else K)
@@ -41,7 +41,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: i
     ws = workspace(nbytes, A.device) if nbytes else None
     call("vqa_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(C), ldc, M, N, K,
          ptr(bias1), ptr(bias2), ptr(rowgroup), (rowgroup.stride(0) if rowgroup is not None else 0),
-         rg_div, rg_op, int(relu), int(accumulate), ptr(ws), (ws.numel() * 4 if ws is not None else 0),
+         rg_div, rg_op, int(relu), int(accumulate), ptr(aux), ptr(ws), (ws.numel() * 4 if ws is not None else 0),
          tag, stream())
     return C
 
@@ -167,21 +167,24 @@ def lstm_cell_bwd(gates, c_in, c_out, q_len, t, dh, dc, dgates):
          B, H, stream())
 
 
-def att_score_fwd(xs, wx, bx, B, P, p: float, seed: int) -> torch.Tensor:
-    G, mid = wx.shape[0], wx.shape[1]
+def att_score_fwd(xs, wx, bx, B, P, p: float, seed: int, qcat=None) -> torch.Tensor:
+    """wx [G, xld] with xld = mid ('+', '*') or 2*mid ('|', qcat = q' [B, mid])."""
+    G, xld = wx.shape[0], wx.shape[1]
+    mid = xld // 2 if qcat is not None else xld
     score = torch.empty(B, G, P, dtype=torch.float32, device=xs.device)
-    call("vqa_att_score_fwd", ptr(xs), ptr(wx), ptr(bx), ptr(score), B, P, mid, G, p, seed, stream())
+    call("vqa_att_score_fwd", ptr(xs), ptr(wx), xld, ptr(bx), ptr(score), B, P, mid, G, p, seed, ptr(qcat), stream())
     return score
 
 
-def att_score_bwd(dscore, wx, xs_inout, B, P, p: float, seed: int):
+def att_score_bwd(dscore, wx, xs_inout, B, P, p: float, seed: int, mode: int = 0, vprime=None, qp=None):
     lib = _lib.load()
-    G, mid = wx.shape[0], wx.shape[1]
+    G, xld = wx.shape[0], wx.shape[1]
+    mid = xld // 2 if mode == 2 else xld
     RS = lib.vqa_att_row_splits(P)
-    dwx_part = torch.empty(B * RS, G * mid, dtype=torch.float32, device=wx.device)
+    dwx_part = torch.empty(B * RS, G * xld, dtype=torch.float32, device=wx.device)
     dq_part = torch.empty(B * RS, mid, dtype=torch.float32, device=wx.device)
-    call("vqa_att_score_bwd", ptr(dscore), ptr(wx), ptr(xs_inout), ptr(dwx_part), ptr(dq_part), B, P, mid, G, p,
-         seed, stream())
+    call("vqa_att_score_bwd", ptr(dscore), ptr(wx), xld, ptr(xs_inout), ptr(dwx_part), ptr(dq_part), B, P, mid, G, p,
+         seed, mode, ptr(vprime), ptr(qp), stream())
     return dwx_part, dq_part, RS
 
 

@@ -67,6 +67,7 @@ int64_t vqa_gemm_workspace_bytes(int M, int N, int K);
 int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
              float* C, int64_t ldc, int M, int N, int K, const float* bias1, const float* bias2,
              const float* rowgroup, int64_t rg_ld, int rg_div, int rg_op, int relu, int accumulate,
+             float* aux /* optional [M][ldc]: the raw product A.B before the epilogue (v' for '*') */,
              float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
 /* ---- image encoder: Conv2d(k=3, stride, pad=0) + ReLU + MaxPool2d(2,2) ----------------------
@@ -134,17 +135,21 @@ int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out,
                       int t, float* dh, float* dc, float* dgates, int B, int H, vqa_stream_t stream);
 
 /* ---- attention (models/model.py:169-195 Attention, 208-221 image_question_attention) ---------
- * xs[m][n] = relu(v'(m,n) (+|*) q'(b,n)) comes from vqa_gemm(rowgroup=q'); then
- * score[b][g][p] = bx[g] + sum_n dropout(xs[b*P+p][n]) * wx[g][n]      (x_conv, model.py:194) */
-int vqa_att_score_fwd(const float* xs, const float* wx, const float* bx, float* score, int B, int P,
-                      int mid, int G, float p, uint64_t seed, vqa_stream_t stream);
-/* In place: xs <- dxpre = (xs > 0) * dropmask * sum_g dscore[b][g][p] wx[g][n]; and per-workgroup
- * partial sums  dwx_part[b*RS+rs][G][mid], dq_part[b*RS+rs][mid]  (RS = vqa_att_row_splits(P)):
- *   dwx = sum over parts of dscore * dropout(xs);  dq' (for '+') = sum over parts of dxpre. */
-int vqa_att_row_splits(int P);
-int vqa_att_score_bwd(const float* dscore, const float* wx, float* xs_inout, float* dwx_part,
-                      float* dq_part, int B, int P, int mid, int G, float p, uint64_t seed,
+ * x = relu(v' (+|*) q') comes from vqa_gemm(rowgroup = q') as xs[m][n]; for do_option '|' (model.py:192)
+ * x = relu(cat[v', tile(q')]) has 2*mid channels: xs holds the v' half and qcat = q' [B][mid] the other.
+ * score[b][g][p] = bx[g] + sum_n dropout(x[b*P+p][n]) * wx[g*wx_ld + n]            (x_conv, model.py:194) */
+int vqa_att_score_fwd(const float* xs, const float* wx, int wx_ld, const float* bx, float* score, int B,
+                      int P, int mid, int G, float p, uint64_t seed, const float* qcat /* '|' only */,
                       vqa_stream_t stream);
+/* Backward of the score + combine stage, in place on xs.  mode: 0 '+', 1 '*', 2 '|'.
+ *   xs      <- gradient w.r.t. v' (what the v_conv dW / dX GEMMs consume)
+ *   dq_part[b*RS+rs][mid]      partial sums of the gradient w.r.t. q' (RS = vqa_att_row_splits(P))
+ *   dwx_part[b*RS+rs][G][xld]  partial sums of the x_conv weight gradient, xld = mid (2*mid for '|')
+ * '*' needs vprime = the raw v' (aux output of the forward GEMM) and qp = q'; '|' needs qp. */
+int vqa_att_row_splits(int P);
+int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, float* xs_inout, float* dwx_part,
+                      float* dq_part, int B, int P, int mid, int G, float p, uint64_t seed, int mode,
+                      const float* vprime, const float* qp, vqa_stream_t stream);
 /* probs = softmax_p(score); out[b*out_ld + g*C + c] = sum_p probs[b][g][p] * vn[b][p][c] */
 int vqa_att_apply_fwd(const float* score, const float* vn, float* probs, float* out, int64_t out_ld,
                       int B, int P, int C, int G, vqa_stream_t stream);

@@ -29,11 +29,11 @@ def test_argument_validation_without_gpu():
     """Host-side checks run before any HIP call, so they are testable on a CPU-only box."""
     from dl_vqa_amd import _lib
     lib = _lib.load()
-    rc = lib.vqa_gemm(None, 4, 0, None, 4, 1, None, 4, 4, 4, 4, None, None, None, 0, 1, 0, 0, 0, None, 0, 0, None)
+    rc = lib.vqa_gemm(None, 4, 0, None, 4, 1, None, 4, 4, 4, 4, None, None, None, 0, 1, 0, 0, 0, None, None, 0, 0, None)
     assert rc == 1 and b"null operand" in lib.vqa_last_error()
     rc = lib.vqa_conv3x3_relu_pool_fwd(16, 16, 16, 16, 16, 1, 8, 8, 6, 8, 1, 0, None)   # CiP = 6
     assert rc == 1 and b"multiples of 4" in lib.vqa_last_error()
-    rc = lib.vqa_att_score_fwd(16, 16, 16, 16, 1, 4, 8, 9, 0.0, 0, None)                 # G = 9
+    rc = lib.vqa_att_score_fwd(16, 16, 8, 16, 16, 1, 4, 8, 9, 0.0, 0, None, None)        # G = 9
     assert rc == 1 and b"glimpses" in lib.vqa_last_error()
     assert lib.vqa_gemm_workspace_bytes(256, 1024, 2560) > 0       # split-K plan for a skinny GEMM
     assert lib.vqa_gemm_workspace_bytes(4096, 4096, 64) == 0

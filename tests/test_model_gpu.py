@@ -11,7 +11,7 @@ from tests.golden_util import TINY_CASES, Golden, full_cfg, full_inputs, tiny_cf
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-HIP_CASES = ["tiny_plus", "tiny_stride2", "tiny_uni", "small64_plus"]   # '+' attention (config.yaml:68)
+HIP_CASES = TINY_CASES   # every reference fixture: '+', '*', '|', stride 2, unidirectional, 64x64
 
 
 # softmax over positions is shift invariant, so d loss / d x_conv.bias is identically zero in exact
@@ -24,8 +24,13 @@ def rel(got, ref):
     return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
 
 
-def grad_err(name, got, ref):
-    if name == ZERO_GRAD:
+# For do_option '|' the question half of x adds the same constant to every position of a glimpse, so (in
+# eval mode) nothing flows back through q_lin either: its gradients are identically zero as well.
+ZERO_GRAD_CAT = ("attention.q_lin.weight", "attention.q_lin.bias")
+
+
+def grad_err(name, got, ref, do_option="+"):
+    if name == ZERO_GRAD or (do_option == "|" and name in ZERO_GRAD_CAT):
         return float((got.detach().double().cpu() - ref.double().cpu()).abs().max()) * 1e2   # |err| < 1e-6 passes 1e-4
     return rel(got, ref)
 
@@ -72,7 +77,7 @@ def test_golden_forward_loss_grads(name):
     assert abs(float(loss) - float(g.t["loss"])) < 1e-5
     assert abs(float(score) - float(g.t["score"])) < 1e-6
     for k, p in m.named_parameters():
-        e = grad_err(k, p.grad, g.grad[k])
+        e = grad_err(k, p.grad, g.grad[k], g.meta["do_option"])
         print(f"[parity] {name} grad {k}: {e:.3e}")
         assert e < 2e-4, (k, e)
     assert float(dict(m.named_parameters())["text.embedding.weight"].grad[0].abs().max()) == 0.0
@@ -226,3 +231,54 @@ def test_cpu_tensors_are_rejected():
     m = VqaNet(cfg, 30)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.randn(1, 3, 32, 32), torch.ones(1, 4, dtype=torch.int64), torch.tensor([4]))
+
+
+@pytest.mark.parametrize("do_option", ["+", "*", "|"])
+def test_train_mode_gradient_matches_finite_difference(do_option):
+    """Train mode (dropout masks fixed by the seed) is a deterministic function of the weights: the HIP
+    backward, masks regenerated from the same counter hash, must agree with a central finite difference of
+    the HIP forward along a random direction over ALL parameters.  Covers the dropout sites of every
+    do_option, which the eval-mode reference fixtures cannot."""
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    from oracle import vqa_oracle as O
+    cfg = tiny_cfg(dict(bidirectional=True, stride=1, do_option=do_option))
+    for sec in ("text", "image", "attention", "classifier"):
+        cfg[sec]["dropout"] = 0.25
+    torch.manual_seed(5)
+    m = build(cfg, 40).train()
+    v, q, a_idx, a_val, _, _, ql = O.synthetic_batch(6, 32, 5, 40, 12, seed=4)
+    v, q, ql, a_idx, a_val = v.to(DEV), q.to(DEV), ql.to(DEV), a_idx.to(DEV), a_val.to(DEV)
+    seed = 987654321
+
+    def loss_at():
+        with torch.no_grad():
+            logits, _ = m._engine.forward(m._param_dict(), v, q, ql, True, seed, keep=False)
+            return float(soft_ce_loss_and_score(logits, a_idx, a_val)[0])
+
+    m._ensure_flat()
+    logits, ctx = m._engine.forward(m._param_dict(), v, q, ql, True, seed, keep=True)
+    B, A = logits.shape
+    dl = torch.zeros(B, A, device=DEV)
+    from dl_vqa_amd import ops
+    ops.softce(logits, A, a_idx, a_val, A, 1.0 / B, dl, A)
+    grads = m._grad_views()
+    m._engine.backward(m._param_dict(), ctx, dl, grads)
+    g = torch.Generator().manual_seed(1)
+    flat_p = m._flat_param
+    direction = torch.zeros_like(flat_p)
+    gdot = 0.0
+    for name, p in m.named_parameters():
+        o, n = m._offsets[name]
+        d = torch.randn(n, generator=g).to(DEV) * float(p.detach().abs().mean() + 1e-3)
+        direction[o:o + n] = d
+        gdot += float((grads[name].reshape(-1).double() * d.double()).sum())
+    eps = 2e-3
+    base = flat_p.clone()
+    flat_p.copy_(base + eps * direction)
+    lp = loss_at()
+    flat_p.copy_(base - eps * direction)
+    lm = loss_at()
+    flat_p.copy_(base)
+    fd = (lp - lm) / (2 * eps)
+    print(f"[parity] train-mode directional derivative ({do_option}): backward {gdot:.6f} vs finite difference {fd:.6f}")
+    assert abs(fd - gdot) <= 0.03 * max(abs(fd), abs(gdot)) + 1e-4

@@ -209,6 +209,15 @@ def main():
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch.value,
                         "algorithmic_gflop_per_launch": round(flops_launch / 1e9, 2)}
+        if roofline is not None and B == 256 and S == 224 and int(tag) == 1:
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+            # rocprofv3 --pmc passes over tools/kbench.py; summary committed under profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_conv1_traffic.json")) as f:
+                    roofline["traffic"] = int(json.load(f)[fam]["hbm_bytes_corrected"])
+                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r01_conv1_traffic.json)"
+            except (OSError, KeyError, ValueError):
+                pass
         gflop_sample = step_flops_per_sample(cfg, S, T) / 1e9
         out = {
             "metric": "VQA samples/sec (train step)", "value": round(value, 2), "unit": "samples/s",

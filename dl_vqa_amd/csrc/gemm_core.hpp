@@ -247,6 +247,7 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const float* const As0 = smem;
   const float* const Bs0 = smem + 2 * BK * Cfg::LDA;
+  __builtin_amdgcn_s_setprio(3);   // MFMA waves win issue arbitration over the loader waves of their SIMD
   __syncthreads();
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;

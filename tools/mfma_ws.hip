@@ -12,6 +12,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters, const float4*
   for (int i = threadIdx.x; i < 16512; i += 512) lds[i] = i * 1e-4f;
   __syncthreads();
   if (threadIdx.x >= 256) {
+    if (LOADS == 4) return;                      // variant: the extra waves leave at once
     const int t = threadIdx.x - 256;
     float4 st[NLOAD];
     for (int i = 0; i < NLOAD; ++i) st[i] = make_float4(1.f, 2.f, 3.f, 4.f);
@@ -109,6 +110,8 @@ void run(const char* name, int blocks_per_cu, size_t foot) {
 
 int main() {
   const size_t L2 = (size_t)1 << 17, BIG = (size_t)1 << 26;
+  run<4, 0, 8>("WS: extra waves exit immediately", 2, L2);
+  run<0, 0, 8>("WS: loaders idle (barrier only)", 1, L2);
   run<0, 0, 8>("WS: loaders idle (barrier only)", 2, L2);
   run<0, 1, 8>("WS: 32 ds_write_b32/thread/step", 2, L2);
   run<1, 0, 8>("WS: 8 loads (2 MiB footprint), no writes", 2, L2);

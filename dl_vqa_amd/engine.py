@@ -61,6 +61,31 @@ class Engine:
         if self.channels[0] > 4:
             raise ValueError("input images with more than 4 channels are not supported")
 
+    # ------------------------------------------------------------------ stream fork / join
+    def _fork_join(self, dev, jobs):
+        """Run independent launch sequences concurrently: job 0 on the current stream, the others on side
+        streams that first wait for everything enqueued so far; the current stream then waits for them."""
+        if len(jobs) == 1:
+            jobs[0]()
+            return
+        main = torch.cuda.current_stream(dev)
+        if not hasattr(self, "_side"):
+            self._side = {}
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for k, job in enumerate(jobs[1:]):
+            side = self._side.setdefault((str(dev), k), torch.cuda.Stream(device=dev))
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                job()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                joins.append(ev)
+        jobs[0]()
+        for ev in joins:
+            main.wait_event(ev)
+
     # ------------------------------------------------------------------ forward
     def forward(self, P: Dict[str, Tensor], v: Tensor, q: Tensor, q_len: Tensor, training: bool, seed: int,
                 keep: bool):
@@ -106,8 +131,9 @@ class Engine:
         p_txt = self.p_text if tr else 0.0
         x_emb = ops.embed_tanh_fwd(q, P["text.embedding.weight"], p_txt, sd(SITE_TEXT))       # [T,B,E]
         combined = new(B, Dc)
-        lstm = []
-        for d in range(self.ndir):
+        lstm = [None] * self.ndir
+
+        def run_direction(d):
             sfx = "_reverse" if d else ""
             w_ih, w_hh = P["text.lstm.weight_ih_l0" + sfx], P["text.lstm.weight_hh_l0" + sfx]
             xg = new(T * B, 4 * H)
@@ -124,7 +150,11 @@ class Engine:
                 last = n == T - 1
                 ops.lstm_cell_fwd(xg[t * B:(t + 1) * B], hg, Cs[si], Hs[si], q_len, t, gates[t], Cs[so], Hs[so],
                                   combined[:, GC + d * H:] if last else None, Dc)
-            lstm.append(SimpleNamespace(gates=gates, Hs=Hs, Cs=Cs))
+            lstm[d] = SimpleNamespace(gates=gates, Hs=Hs, Cs=Cs, xg=xg, hg=hg)
+
+        # the two directions are independent chains of small (M = B) GEMMs that each fill only half the
+        # chip: run them on two HIP streams so their workgroups share the CUs
+        self._fork_join(dev, [lambda d=d: run_direction(d) for d in range(self.ndir)])
         qf = combined[:, GC:]
 
         # ---- attention (model.py:183-195): v' = v_conv(drop(v)), q' = q_lin(drop(q)), x = relu(v' + q')
@@ -241,8 +271,9 @@ class Engine:
         ready("attention")
 
         # ---- LSTM (BPTT over the masked steps), embedding
-        dx_emb = new(T * B, E)
-        for d in range(self.ndir):
+        dx_parts = [new(T * B, E) for _ in range(self.ndir)]
+
+        def bptt(d):
             sfx = "_reverse" if d else ""
             st = ctx.lstm[d]
             w_ih, w_hh = P["text.lstm.weight_ih_l0" + sfx], P["text.lstm.weight_hh_l0" + sfx]
@@ -263,7 +294,13 @@ class Engine:
                      lda=4 * H, ldb=E, tag=52)
             ops.colsum(dgates, T * B, 4 * H, Gr["text.lstm.bias_ih_l0" + sfx])
             ops.add2d(Gr["text.lstm.bias_ih_l0" + sfx], 4 * H, None, 0, Gr["text.lstm.bias_hh_l0" + sfx], 4 * H, 1, 4 * H)
-            ops.gemm(dgates, w_ih, dx_emb, T * B, E, 4 * H, transB=False, lda=4 * H, ldb=E, accumulate=(d > 0), tag=53)
+            ops.gemm(dgates, w_ih, dx_parts[d], T * B, E, 4 * H, transB=False, lda=4 * H, ldb=E, tag=53)
+            st.dgates = dgates          # keep alive until the streams have joined
+
+        self._fork_join(dev, [lambda d=d: bptt(d) for d in range(self.ndir)])
+        dx_emb = dx_parts[0]
+        if self.ndir > 1:
+            ops.add(dx_parts[0], dx_parts[1], dx_emb)
         demb = Gr["text.embedding.weight"]
         demb.zero_()
         ops.embed_tanh_bwd(ctx.q, ctx.x_emb, dx_emb, demb, ctx.p_txt, sd(SITE_TEXT))

@@ -16,8 +16,9 @@ _ws = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """A per-device scratch buffer that only grows (split-K slabs, reduction partials)."""
-    key = str(device)
+    """A scratch buffer that only grows (split-K slabs, reduction partials), one per (device, stream):
+    launch sequences that run concurrently on different HIP streams must not share slabs."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     t = _ws.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = torch.empty(max(nbytes // 4 + 1024, 1 << 20), dtype=torch.float32, device=device)

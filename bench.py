@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--vocab", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="diagnostic only: dropout off")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="diagnostic: take the RCCL data-parallel path even with one rank (under torchrun)")
     ap.add_argument("--roofline-kernel", default="conv_wgrad:1",
                     help="kernel family:tag timed live with HIP events (conv_fwd|conv_dgrad|conv_wgrad : layer)")
     args = ap.parse_args()
@@ -140,7 +142,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     from dl_vqa_amd import VqaNet, _lib
@@ -154,7 +157,7 @@ def main():
     torch.manual_seed(1)                                   # config.yaml:9 seed
     model = VqaNet(cfg, V).to(dev)
     model.train(not args.eval_mode)
-    if world > 1:
+    if use_dist:
         DataParallel(model)
     batch = tuple(t.to(dev) for t in synthetic_batch(B, S, T, V, A, seed=1 + rank))
     opt = FusedAdam(model, lr=5e-4)
@@ -174,7 +177,7 @@ def main():
     fam, tag = args.roofline_kernel.split(":")
     fam_id = {"gemm": 0, "conv_fwd": 1, "conv_dgrad": 2, "conv_wgrad": 3}[fam]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     lib.vqa_prof_arm(fam_id, int(tag))
     torch.cuda.synchronize()
@@ -182,18 +185,18 @@ def main():
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     import ctypes
     n_launch, tot_ms = ctypes.c_int(0), ctypes.c_float(0.0)
     lib.vqa_prof_read(ctypes.byref(n_launch), ctypes.byref(tot_ms))
     lib.vqa_prof_arm(-1, -1)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -223,7 +226,7 @@ def main():
             "metric": "VQA samples/sec (train step)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"VqaNet train step (fwd+softCE+bwd+{'allreduce+' if world > 1 else ''}Adam), "
+            "config": {"workload": f"VqaNet train step (fwd+softCE+bwd+{'allreduce+' if use_dist else ''}Adam), "
                                    f"batch {B}/GPU, {S}x{S} images, {T}-token questions, {A}-way head, "
                                    f"{'eval' if args.eval_mode else 'train'} mode",
                        "global_batch": B * world, "image_size": S, "tokens": T, "answers": A, "vocab": V,
@@ -236,7 +239,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, V, A, T)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -28,8 +28,8 @@ using Cfg128 = TileCfg<128, 128, 2, 2>;
 using Cfg128x64 = TileCfg<128, 64, 2, 2>;
 // 256-row tiles for the pixel-major GEMMs (forward / dgrad: M = millions of pixels): 25 % fewer bytes
 // staged per MFMA than 128x128 (tools/mfma_ws.hip: 83 % -> 88 % of the MFMA rate in the same skeleton).
-using Cfg256x128 = TileCfg<256, 128, 2, 2>;
-using Cfg256x64 = TileCfg<256, 64, 2, 2>;
+using Cfg256x128 = TileCfg<256, 128, 4, 2>;   // 8 MFMA waves (64x64 each) + 4 loader waves, one workgroup per CU
+using Cfg256x64 = TileCfg<256, 64, 4, 2>;     // 8 MFMA waves (64x32 each)
 using Cfg64 = TileCfg<64, 64, 2, 2>;
 
 template <class K>
@@ -48,7 +48,7 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   auto kern = conv_fwd_kernel<Cfg>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_fwd)"); if (rc) return rc; done = true; }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), Cfg::SMEM_BYTES, s, pa, pb, bias, pooled, amax,
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, bias, pooled, amax,
                      g.Co, tiles_m, tiles_n, (K + BK - 1) / BK);
   return check_hip(hipGetLastError(), "conv_fwd launch");
 }
@@ -63,7 +63,7 @@ static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, flo
   auto kern = conv_dgrad_kernel<Cfg>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_dgrad)"); if (rc) return rc; done = true; }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), Cfg::SMEM_BYTES, s, pa, pb, dx, g.CiP, tiles_m,
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, dx, g.CiP, tiles_m,
                      tiles_n, (K + BK - 1) / BK);
   return check_hip(hipGetLastError(), "conv_dgrad launch");
 }
@@ -99,7 +99,7 @@ static int launch_wgrad(const float* x, const float* dp, const uint8_t* am, floa
   auto kern = conv_wgrad_kernel<Cfg>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_wgrad)"); if (rc) return rc; done = true; }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), Cfg::SMEM_BYTES, s, pa, pb, slab,
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, slab,
                      bias_slab, p.tiles_m, p.tiles_n, p.nk, p.ks_per_split);
   return check_hip(hipGetLastError(), "conv_wgrad launch");
 }
@@ -145,9 +145,11 @@ int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias
   if (rc) return rc;
   set_launch_tag(tag);
   ProfScope prof(VQA_K_CONV_FWD, (hipStream_t)stream);
-  // 256-row tiles measured SLOWER in the real kernels (one workgroup per CU: the loader waves become the
-  // critical path: conv1 fwd 72 % vs 73.5 %, dgrad 46-56 % vs 62-67 %), so they stay compiled but unused.
-  const bool many_rows = false;
+  // 256x128 tiles (8 MFMA waves + 4 loader waves, one workgroup per CU) measured +2 % on forward (74-75 %
+  // vs 72-73 %), whose loader is cheap; on dgrad the routing loader becomes the critical path with only one
+  // loader wave per SIMD (51-62 % vs 64-70 %), so dgrad keeps 128-row tiles.  VQA_BIG_TILES=0/1 overrides.
+  const char* bt = getenv("VQA_BIG_TILES");
+  const bool many_rows = (int64_t)4 * B * g.Hp * g.Wp >= 256 * 1024 && !(bt && bt[0] == '0');
   if (Co > 64) return many_rows ? launch_fwd<Cfg256x128>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream)
                                 : launch_fwd<Cfg128>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
   return launch_fwd<Cfg128x64>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
@@ -161,7 +163,8 @@ int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* 
   if (rc) return rc;
   set_launch_tag(tag);
   ProfScope prof(VQA_K_CONV_DGRAD, (hipStream_t)stream);
-  const bool many_rows = false;   // see vqa_conv3x3_relu_pool_fwd
+  const char* bt = getenv("VQA_BIG_TILES");
+  const bool many_rows = (int64_t)B * H * W >= 256 * 1024 && bt && bt[0] == '1';   // see vqa_conv3x3_relu_pool_fwd
   if (CiP > 64) return many_rows ? launch_dgrad<Cfg256x128>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
                                  : launch_dgrad<Cfg128>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
   return many_rows ? launch_dgrad<Cfg256x64>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)

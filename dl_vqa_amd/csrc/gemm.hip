@@ -68,7 +68,7 @@ __device__ __forceinline__ float epi_apply(const EpiParams& e, float v, int row,
 }
 
 template <class Cfg, class AL, class BL>
-__global__ __launch_bounds__(512, Cfg::MIN_WAVES) void gemm_kernel(typename AL::Params pa, typename BL::Params pb,
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_kernel(typename AL::Params pa, typename BL::Params pb,
                                                    EpiParams pe, int tiles_m, int tiles_n, int nk,
                                                    int ks_per_split, int Ktot) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(512, Cfg::MIN_WAVES) void gemm_kernel(typename AL::
   const int split = tc.split;
   const int ks0 = split * ks_per_split;
   const int ks1 = min(nk, ks0 + ks_per_split);
-  AL al; al.init(pa, m0, tid & 255, ks0);
-  BL bl; bl.init(pb, n0, tid & 255, ks0);
+  AL al; al.init(pa, m0, loader_tid<Cfg>(), ks0);
+  BL bl; bl.init(pb, n0, loader_tid<Cfg>(), ks0);
   f32x16 acc[Cfg::TM][Cfg::TN];
   acc_zero<Cfg>(acc);
   if (!gemm_mainloop<Cfg>(al, bl, acc, ks0, ks1, Ktot, smem)) return;
@@ -161,7 +161,7 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
     attr_done = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n * p.splits);
-  hipLaunchKernelGGL(kern, grid, dim3(512), Cfg::SMEM_BYTES, s, pa, pb, pe, p.tiles_m, p.tiles_n, p.nk,
+  hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, pe, p.tiles_m, p.tiles_n, p.nk,
                      p.ks_per_split, K);
   return check_hip(hipGetLastError(), "gemm_kernel launch");
 }

@@ -34,7 +34,7 @@ constexpr int BK = 32;  // K-step depth (floats): 8 lanes x 16 B = one 128-B lin
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
 struct TileCfg {
-  static_assert(WAVES_M_ * WAVES_N_ == 4, "4 waves per workgroup");
+  static_assert(WAVES_M_ * WAVES_N_ == 4 || WAVES_M_ * WAVES_N_ == 8, "4 or 8 MFMA waves per workgroup");
   static constexpr int BM = BM_, BN = BN_;
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -46,7 +46,10 @@ struct TileCfg {
   static constexpr int SMEM_BYTES = SMEM_FLOATS * 4;
   // waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
   // two 512-thread workgroups per CU (4 waves/SIMD, <= 128 VGPRs) up to 128x128, one above that
-  static constexpr int MIN_WAVES = (BM * BN > 128 * 128) ? 2 : 4;
+  static constexpr int NMFMA = WAVES_M * WAVES_N;          // MFMA waves (threads 0 .. 64*NMFMA-1)
+  static constexpr int MFMA_THREADS = 64 * NMFMA;
+  static constexpr int THREADS = MFMA_THREADS + 256;       // + 4 loader waves
+  static constexpr int MIN_WAVES = (THREADS / 256) * ((SMEM_BYTES > 80 * 1024) ? 1 : 2);
 };
 
 // Thread -> staging coordinates, common to both loader types.
@@ -157,8 +160,6 @@ struct PlainC {
 // peak in the same micro-benchmark).  A global load has a full K-step (>= 4096 MFMA cycles) to land.
 // The two roles are separate loops (not one loop with a role test) so that each gets its own register
 // allocation: accumulators + fragments for one, Raw tiles + addresses for the other, both <= 128 VGPRs.
-constexpr int kThreads = 512;
-constexpr int kLoaderThreads = 256;
 
 // NS k2-steps from one LDS image; fragments are fetched a group of 4 k2-steps ahead of their MFMAs.
 template <class Cfg, int NS>
@@ -210,14 +211,15 @@ __device__ __forceinline__ void stage_store_one(const L& ld, const typename L::R
   if (L::kTypeR) lds_store_R<LD, NV>(dst, r, ltid); else lds_store_C<LD, NV>(dst, r, ltid);
 }
 
-__device__ __forceinline__ bool is_loader_wave() { return threadIdx.x >= kLoaderThreads; }
-// staging thread id of a loader thread (0..255); loaders are waves 4..7
-__device__ __forceinline__ int loader_tid() { return threadIdx.x - kLoaderThreads; }
+template <class Cfg> __device__ __forceinline__ bool is_loader_wave() { return threadIdx.x >= Cfg::MFMA_THREADS; }
+// staging thread id (0..255): the loader waves are the last four of the workgroup; MFMA waves get a
+// harmless in-range value (they construct loaders but never use them)
+template <class Cfg> __device__ __forceinline__ int loader_tid() { return (threadIdx.x - Cfg::MFMA_THREADS) & 255; }
 
 // Loader role: K-steps [ks0, ks1).  Loaders tolerate issue() past the end (addresses clamped, data masked).
 template <class Cfg, class AL, class BL>
 __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, float* smem) {
-  const int ltid = loader_tid();
+  const int ltid = loader_tid<Cfg>();
   float* const As0 = smem;
   float* const Bs0 = smem + 2 * BK * Cfg::LDA;
   typename AL::Raw rawA;
@@ -265,7 +267,7 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
 template <class Cfg, class AL, class BL, bool SHORT_TAIL = false>
 __device__ __forceinline__ bool gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
                                               int Ktot, float* smem) {
-  if (is_loader_wave()) {
+  if (is_loader_wave<Cfg>()) {
     loader_loop<Cfg>(al, bl, ks0, ks1, smem);
     return false;
   }

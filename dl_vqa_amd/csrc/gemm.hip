@@ -132,16 +132,23 @@ static GemmPlan plan_gemm(int M, int N, int K) {
     // few big tiles + many splits = short K loops dominated by prologue/epilogue (LSTM dh GEMM, M = 256:
     // 16 tiles x 24 splits of 6 K-steps ran at 21 % of peak): below 64 big tiles use 64x64 tiles, whose
     // 4x larger tile count needs 4x fewer splits
-    p.big = (M >= 128 && N >= 128 && t128 >= 64) ? 1 : 0;
+    // ... unless K is long enough that every split of the big tiling still runs >= 16 K-steps
+    // (v_conv dW: K = B*P = 173k -> 16 tiles x 24 splits x 225 K-steps: 128x128 is 13 % faster there)
+    const int big_splits = (384 + t128 - 1) / t128;
+    p.big = (M >= 128 && N >= 128 && (t128 >= 64 || nk / big_splits >= 16)) ? 1 : 0;
     const int tiles = p.big ? t128 : t64;
     const int max_splits = nk / 4 > 1 ? nk / 4 : 1;
     splits = (384 + tiles - 1) / tiles;
     if (splits > max_splits) splits = max_splits;
     if (splits > 64) splits = 64;
   }
-  const int bm = p.big ? 128 : 64;
+  // 256x128 tiles (8 MFMA waves, as the conv forward) measured 4-8 % SLOWER on the tall plain GEMMs
+  // (v_conv fwd 1.29 vs 1.24 ms, dgrad 0.94 vs 0.87 ms): opt-in only (VQA_BIG_TILES=2)
+  const char* bt = getenv("VQA_BIG_TILES");
+  if (p.big && splits == 1 && ((M + 255) / 256) * ((N + 127) / 128) >= 512 && bt && bt[0] == '2') p.big = 2;
+  const int bm = p.big == 2 ? 256 : (p.big ? 128 : 64), bn = p.big ? 128 : 64;
   p.tiles_m = (M + bm - 1) / bm;
-  p.tiles_n = (N + bm - 1) / bm;
+  p.tiles_n = (N + bn - 1) / bn;
   p.nk = nk;
   p.ks_per_split = (nk + splits - 1) / splits;
   p.splits = (nk + p.ks_per_split - 1) / p.ks_per_split;
@@ -167,6 +174,7 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
 }
 
 using Cfg128 = TileCfg<128, 128, 2, 2>;
+using Cfg256 = TileCfg<256, 128, 4, 2>;
 using Cfg64 = TileCfg<64, 64, 2, 2>;
 
 template <class Cfg>
@@ -250,8 +258,9 @@ int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ld
   int rc;
   {
     ProfScope prof(VQA_K_GEMM, s);
-    rc = p.big ? dispatch_gemm<Cfg128>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s)
-               : dispatch_gemm<Cfg64>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s);
+    rc = p.big == 2 ? dispatch_gemm<Cfg256>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s)
+         : p.big  ? dispatch_gemm<Cfg128>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s)
+                  : dispatch_gemm<Cfg64>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s);
     if (rc) return rc;
     if (p.splits > 1) {
       const int64_t total = (int64_t)M * N;

@@ -70,11 +70,11 @@ __device__ __forceinline__ float epi_apply(const EpiParams& e, float v, int row,
 template <class Cfg, class AL, class BL>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_kernel(typename AL::Params pa, typename BL::Params pb,
                                                    EpiParams pe, int tiles_m, int tiles_n, int nk,
-                                                   int ks_per_split, int Ktot) {
+                                                   int ks_per_split, int Ktot, int order, int splits) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-  const TileCoord tc = tile_coord(tiles_m, tiles_n);
+  const TileCoord tc = tile_coord(tiles_m, tiles_n, order, splits);
   const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
   const int split = tc.split;
   const int ks0 = split * ks_per_split;
@@ -118,7 +118,7 @@ __global__ void splitk_reduce_kernel(EpiParams pe, int splits) {
 }
 
 // ------------------------------------------------------------------ host side
-struct GemmPlan { int big; int tiles_m, tiles_n, nk, splits, ks_per_split; };
+struct GemmPlan { int big; int tiles_m, tiles_n, nk, splits, ks_per_split, order; };
 
 static GemmPlan plan_gemm(int M, int N, int K) {
   GemmPlan p;
@@ -152,6 +152,9 @@ static GemmPlan plan_gemm(int M, int N, int K) {
   p.nk = nk;
   p.ks_per_split = (nk + splits - 1) / splits;
   p.splits = (nk + p.ks_per_split - 1) / p.ks_per_split;
+  // skinny GEMM with a big B operand: keep each XCD on its own column slice of B (tile_coord order 1)
+  const char* wo = getenv("VQA_WEIGHT_STATIONARY");
+  p.order = (p.tiles_m <= 8 && p.tiles_n >= 16 && !(wo && wo[0] == '0')) ? 1 : 0;
   return p;
 }
 
@@ -169,7 +172,7 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
   }
   dim3 grid(p.tiles_m * p.tiles_n * p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, pe, p.tiles_m, p.tiles_n, p.nk,
-                     p.ks_per_split, K);
+                     p.ks_per_split, K, p.order, p.splits);
   return check_hip(hipGetLastError(), "gemm_kernel launch");
 }
 

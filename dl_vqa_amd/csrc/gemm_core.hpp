@@ -50,6 +50,10 @@ struct TileCfg {
   static constexpr int MFMA_THREADS = 64 * NMFMA;
   static constexpr int THREADS = MFMA_THREADS + 256;       // + 4 loader waves
   static constexpr int MIN_WAVES = (THREADS / 256) * ((SMEM_BYTES > 80 * 1024) ? 1 : 2);
+  // K-steps of global loads a loader thread keeps in flight (register ring).  A 64x64 tile's K-step is
+  // only 1024 MFMA cycles (~0.45 us), shorter than an L2 round trip, so it needs 3 steps of run-ahead;
+  // the big tiles' K-steps (>= 4096 cycles) cover the latency with one and have no registers to spare.
+  static constexpr int PREFETCH = (BM * BN <= 64 * 64) ? 3 : 1;
 };
 
 // Thread -> staging coordinates, common to both loader types.
@@ -217,27 +221,38 @@ template <class Cfg> __device__ __forceinline__ bool is_loader_wave() { return t
 template <class Cfg> __device__ __forceinline__ int loader_tid() { return (threadIdx.x - Cfg::MFMA_THREADS) & 255; }
 
 // Loader role: K-steps [ks0, ks1).  Loaders tolerate issue() past the end (addresses clamped, data masked).
+// Ring of D = Cfg::PREFETCH Raw register sets: at K-step ks the tile of step ks+1 is written to the other
+// LDS buffer and the loads of step ks+1+D are issued into the set it frees.
 template <class Cfg, class AL, class BL>
 __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, float* smem) {
+  constexpr int D = Cfg::PREFETCH;
   const int ltid = loader_tid<Cfg>();
   float* const As0 = smem;
   float* const Bs0 = smem + 2 * BK * Cfg::LDA;
-  typename AL::Raw rawA;
-  typename BL::Raw rawB;
-  al.issue(ks0, rawA);
-  bl.issue(ks0, rawB);
-  stage_store_one<Cfg, AL, true>(al, rawA, As0, ltid);
-  stage_store_one<Cfg, BL, false>(bl, rawB, Bs0, ltid);
-  al.issue(ks0 + 1, rawA);
-  bl.issue(ks0 + 1, rawB);
+  typename AL::Raw rawA[D];
+  typename BL::Raw rawB[D];
+  al.issue(ks0, rawA[0]);
+  bl.issue(ks0, rawB[0]);
+  stage_store_one<Cfg, AL, true>(al, rawA[0], As0, ltid);
+  stage_store_one<Cfg, BL, false>(bl, rawB[0], Bs0, ltid);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    al.issue(ks0 + 1 + d, rawA[d]);
+    bl.issue(ks0 + 1 + d, rawB[d]);
+  }
   __syncthreads();
-  for (int ks = ks0; ks < ks1; ++ks) {
-    const int nxt = ((ks - ks0) & 1) ^ 1;
-    stage_store_one<Cfg, AL, true>(al, rawA, As0 + nxt * (BK * Cfg::LDA), ltid);
-    al.issue(ks + 2, rawA);
-    stage_store_one<Cfg, BL, false>(bl, rawB, Bs0 + nxt * (BK * Cfg::LDB), ltid);
-    bl.issue(ks + 2, rawB);
-    __syncthreads();
+  for (int ks = ks0; ks < ks1; ks += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (ks + d < ks1) {                                 // block-uniform; one barrier per K-step, as the MFMA role
+        const int nxt = ((ks + d - ks0) & 1) ^ 1;
+        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * (BK * Cfg::LDA), ltid);
+        al.issue(ks + d + 1 + D, rawA[d]);
+        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * (BK * Cfg::LDB), ltid);
+        bl.issue(ks + d + 1 + D, rawB[d]);
+        __syncthreads();
+      }
+    }
   }
 }
 
@@ -300,11 +315,22 @@ __device__ __forceinline__ int acc_col(int wn, int j, int lane) {
 // Workgroup id -> (mt, nt, split).  The grid is one-dimensional; logical ids run nt fastest, then
 // mt, then split, and xcd_swizzle gives each XCD a contiguous range of logical ids: workgroups that
 // share an A panel (same mt) or the same reduction slice (same split) meet in one XCD's L2.
+// order 1 ("weight stationary", for skinny GEMMs whose B operand is the big one, e.g. the LSTM's
+// h[256 x 1024] . W_hh^T[1024 x 4096]): nt runs SLOWEST, so an XCD's contiguous id range covers only
+// tiles_n/8 column tiles and re-reads just that 1/8 slice of the weights, which then fits its 4 MiB L2.
 struct TileCoord { int mt, nt, split; };
-__device__ __forceinline__ TileCoord tile_coord(int tiles_m, int tiles_n) {
+__device__ __forceinline__ TileCoord tile_coord(int tiles_m, int tiles_n, int order = 0, int splits = 1) {
   const int t = xcd_swizzle(blockIdx.x, gridDim.x);
   const int tiles = tiles_m * tiles_n;
   TileCoord c;
+  if (order == 1) {
+    const int per_nt = tiles_m * splits;
+    c.nt = t / per_nt;
+    const int u = t - c.nt * per_nt;
+    c.split = u / tiles_m;
+    c.mt = u - c.split * tiles_m;
+    return c;
+  }
   c.split = t / tiles;
   const int u = t - c.split * tiles;
   c.mt = u / tiles_n;

@@ -63,10 +63,11 @@ class Engine:
             raise ValueError("input images with more than 4 channels are not supported")
 
     def _side_streams(self, dev):
-        # VQA_STREAMS=2 runs each LSTM direction on a side stream under the convolutions.  Measured on one
-        # MI355X (same box, interleaved): 33.35 ms/step with side streams vs 33.17 ms on one stream — the
-        # chip is already saturated by the conv kernels, so the default keeps a single stream.
-        mode = os.environ.get("VQA_STREAMS", "0")
+        # VQA_STREAMS: 0 = one stream; 1 (default) = the two LSTM directions on two side streams, joined before
+        # the image branch; 2 = additionally under the convolutions.  Same box, interleaved, ms/step:
+        # 32.75 / 32.24 / 32.76 — the small M = 256 step GEMMs each fill half the chip, so pairing them helps,
+        # while the conv kernels already saturate it.
+        mode = os.environ.get("VQA_STREAMS", "1")
         if mode == "0":
             cur = torch.cuda.current_stream(dev)
             return [cur, cur]
@@ -156,6 +157,9 @@ class Engine:
                 ev = torch.cuda.Event()
                 ev.record(sides[d])
                 text_done.append(ev)
+        if os.environ.get("VQA_STREAMS", "1") == "1":     # directions concurrent with each other only
+            for ev in text_done:
+                main.wait_event(ev)
         # ---- image encoder: conv+relu+pool x L (models/model.py:79-84)
         # the first block has a dedicated kernel that reads the NCHW image as is (K = 27 is too thin for the
         # generic implicit GEMM); otherwise the image is converted to NHWC4 once
@@ -353,6 +357,8 @@ class Engine:
             ready("text")
             ev0 = torch.cuda.Event()
             ev0.record(sides[0])
+        if os.environ.get("VQA_STREAMS", "1") == "1":
+            main.wait_event(ev0)
 
         # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first
         dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE)).view_as(ctx.acts[-1])

@@ -40,9 +40,11 @@ struct TileCfg {
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   static constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile = 32x32 MFMA tiles");
-  static constexpr int LDA = BM + 1, LDB = BN + 1;  // == 1 (mod 32): conflict-free transposing writes
   static constexpr int NVA = BM / 32, NVB = BN / 32;  // float4 per thread per K-step
-  static constexpr int SMEM_FLOATS = 2 * BK * (LDA + LDB);
+  // One LDS buffer per operand per stage.  Its image depends on the operand's loader type (LdsImage):
+  // both forms fit in 36 floats per row/column of the tile.
+  static constexpr int ABUF = 36 * BM, BBUF = 36 * BN;      // floats
+  static constexpr int SMEM_FLOATS = 2 * (ABUF + BBUF);
   static constexpr int SMEM_BYTES = SMEM_FLOATS * 4;
   // waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
   // two 512-thread workgroups per CU (4 waves/SIMD, <= 128 VGPRs) up to 128x128, one above that
@@ -56,27 +58,32 @@ struct TileCfg {
   static constexpr int PREFETCH = (BM * BN <= 64 * 64) ? 3 : 1;
 };
 
+// LDS images.  An fp32 MFMA fragment is one dword per lane and the K order inside a K-step is free as
+// long as A and B agree, so MFMA q (0..3) of group t (0..3) takes k = 8t + 4h + q (h = lane >> 5):
+//   type R operand (k-contiguous rows in memory): image [row][RS = 36]; a thread's 16-byte chunk is ONE
+//     ds_write_b128 (8 lanes = one 128-B row segment), and a lane fetches the four k of a group with ONE
+//     ds_read_b128 at row*36 + 8t + 4h: 16 rows x 36-dword stride cover the 64 banks exactly once.
+//   type C operand (reduction-major in memory): image [k][CS = tile + 4]; ONE ds_write_b128 per chunk
+//     and stride-1 ds_read_b32 over the 32 lanes at row k = 8t + 4h + q.
+// Both are conflict-free, and both need 4x fewer LDS write instructions than a transposing b32 image.
+constexpr int LDS_RS = 36;
+template <int TILE> struct LdsImage { static constexpr int CS = TILE + 4; };
+
 // Thread -> staging coordinates, common to both loader types.
 //   r32 = tid >> 3 (0..31), c8 = tid & 7 (0..7)
-// type R: rows r32 + 32*p (p < BM/32), k-chunk c8 (k = 4*c8 .. 4*c8+3)
-// type C: k-row r32, m-chunks c8 + 8*p (m = 4*(c8+8p) .. +3)
-template <int LD, int NV>
+// type R: rows r32 + 32*p (p < TILE/32), k-chunk c8 (k = 4*c8 .. 4*c8+3)
+// type C: k-row r32, chunks c8 + 8*p (tile elements 4*(c8+8p) .. +3)
+template <int TILE, int NV>
 __device__ __forceinline__ void lds_store_R(float* s, const float4 (&r)[NV], int tid) {
   const int r32 = tid >> 3, c8 = tid & 7;
 #pragma unroll
-  for (int p = 0; p < NV; ++p) {
-    float* d = s + (4 * c8) * LD + r32 + 32 * p;
-    d[0] = r[p].x; d[LD] = r[p].y; d[2 * LD] = r[p].z; d[3 * LD] = r[p].w;
-  }
+  for (int p = 0; p < NV; ++p) *reinterpret_cast<float4*>(s + (r32 + 32 * p) * LDS_RS + 4 * c8) = r[p];
 }
-template <int LD, int NV>
+template <int TILE, int NV>
 __device__ __forceinline__ void lds_store_C(float* s, const float4 (&r)[NV], int tid) {
   const int r32 = tid >> 3, c8 = tid & 7;
 #pragma unroll
-  for (int p = 0; p < NV; ++p) {
-    float* d = s + r32 * LD + 4 * (c8 + 8 * p);
-    d[0] = r[p].x; d[1] = r[p].y; d[2] = r[p].z; d[3] = r[p].w;
-  }
+  for (int p = 0; p < NV; ++p) *reinterpret_cast<float4*>(s + r32 * LdsImage<TILE>::CS + 4 * (c8 + 8 * p)) = r[p];
 }
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -165,43 +172,51 @@ struct PlainC {
 // The two roles are separate loops (not one loop with a role test) so that each gets its own register
 // allocation: accumulators + fragments for one, Raw tiles + addresses for the other, both <= 128 VGPRs.
 
-// NS k2-steps from one LDS image; fragments are fetched a group of 4 k2-steps ahead of their MFMAs.
-template <class Cfg, int NS>
+// NG groups of 4 k2-steps from one stage; the fragments of group t+1 are fetched before the MFMAs of group t.
+template <class Cfg, bool AR, bool BR, int NG>
 __device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x16 (&acc)[Cfg::TM][Cfg::TN],
                                           int wm, int wn, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
-  const float* ap = As + h * Cfg::LDA + wm * Cfg::WM + l31;
-  const float* bp = Bs + h * Cfg::LDB + wn * Cfg::WN + l31;
-  constexpr int GS = 4, NG = NS / GS;
-  static_assert(NS % GS == 0, "k2-steps come in groups of 4");
-  float a[2][GS][Cfg::TM], b[2][GS][Cfg::TN];
+  constexpr int CSA = LdsImage<Cfg::BM>::CS, CSB = LdsImage<Cfg::BN>::CS;
+  // group t, MFMA q: k = 8t + 4h + q
+  const float* ap = AR ? As + (wm * Cfg::WM + l31) * LDS_RS + 4 * h : As + 4 * h * CSA + wm * Cfg::WM + l31;
+  const float* bp = BR ? Bs + (wn * Cfg::WN + l31) * LDS_RS + 4 * h : Bs + 4 * h * CSB + wn * Cfg::WN + l31;
+  float a[2][4][Cfg::TM], b[2][4][Cfg::TN];
+  auto fetch = [&](int t, int buf) {
 #pragma unroll
-  for (int s = 0; s < GS; ++s) {
+    for (int i = 0; i < Cfg::TM; ++i) {
+      if (AR) {
+        const float4 v = *reinterpret_cast<const float4*>(ap + 32 * i * LDS_RS + 8 * t);
+        a[buf][0][i] = v.x; a[buf][1][i] = v.y; a[buf][2][i] = v.z; a[buf][3][i] = v.w;
+      } else {
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i) a[0][s][i] = ap[2 * s * Cfg::LDA + 32 * i];
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) b[0][s][j] = bp[2 * s * Cfg::LDB + 32 * j];
-  }
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int cur = g & 1, nxt = cur ^ 1;
-    if (g + 1 < NG) {
-#pragma unroll
-      for (int s = 0; s < GS; ++s) {
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i) a[nxt][s][i] = ap[2 * ((g + 1) * GS + s) * Cfg::LDA + 32 * i];
-#pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) b[nxt][s][j] = bp[2 * ((g + 1) * GS + s) * Cfg::LDB + 32 * j];
+        for (int q = 0; q < 4; ++q) a[buf][q][i] = ap[(8 * t + q) * CSA + 32 * i];
       }
     }
-    __builtin_amdgcn_sched_barrier(0);   // reads of group g+1 stay above the MFMAs of group g
 #pragma unroll
-    for (int s = 0; s < GS; ++s)
+    for (int j = 0; j < Cfg::TN; ++j) {
+      if (BR) {
+        const float4 v = *reinterpret_cast<const float4*>(bp + 32 * j * LDS_RS + 8 * t);
+        b[buf][0][j] = v.x; b[buf][1][j] = v.y; b[buf][2][j] = v.z; b[buf][3][j] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[buf][q][j] = bp[(8 * t + q) * CSB + 32 * j];
+      }
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int t = 0; t < NG; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NG) fetch(t + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);   // reads of group t+1 stay above the MFMAs of group t
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][s][i], b[cur][s][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q][i], b[cur][q][j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -209,10 +224,10 @@ __device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x
 template <class Cfg, class L, bool IS_A>
 __device__ __forceinline__ void stage_store_one(const L& ld, const typename L::Raw& raw, float* dst, int ltid) {
   constexpr int NV = IS_A ? Cfg::NVA : Cfg::NVB;
-  constexpr int LD = IS_A ? Cfg::LDA : Cfg::LDB;
+  constexpr int TILE = IS_A ? Cfg::BM : Cfg::BN;
   float4 r[NV];
   ld.finish(raw, r);
-  if (L::kTypeR) lds_store_R<LD, NV>(dst, r, ltid); else lds_store_C<LD, NV>(dst, r, ltid);
+  if (L::kTypeR) lds_store_R<TILE, NV>(dst, r, ltid); else lds_store_C<TILE, NV>(dst, r, ltid);
 }
 
 template <class Cfg> __device__ __forceinline__ bool is_loader_wave() { return threadIdx.x >= Cfg::MFMA_THREADS; }
@@ -228,7 +243,7 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
   constexpr int D = Cfg::PREFETCH;
   const int ltid = loader_tid<Cfg>();
   float* const As0 = smem;
-  float* const Bs0 = smem + 2 * BK * Cfg::LDA;
+  float* const Bs0 = smem + 2 * Cfg::ABUF;
   typename AL::Raw rawA[D];
   typename BL::Raw rawB[D];
   al.issue(ks0, rawA[0]);
@@ -246,9 +261,9 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
     for (int d = 0; d < D; ++d) {
       if (ks + d < ks1) {                                 // block-uniform; one barrier per K-step, as the MFMA role
         const int nxt = ((ks + d - ks0) & 1) ^ 1;
-        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * (BK * Cfg::LDA), ltid);
+        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * Cfg::ABUF, ltid);
         al.issue(ks + d + 1 + D, rawA[d]);
-        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * (BK * Cfg::LDB), ltid);
+        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * Cfg::BBUF, ltid);
         bl.issue(ks + d + 1 + D, rawB[d]);
         __syncthreads();
       }
@@ -257,21 +272,21 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
 }
 
 // MFMA role.  SHORT_TAIL (conv0 forward, K = 36 = 32 + 4): the last K-step runs 4 k2-steps instead of 16.
-template <class Cfg, bool SHORT_TAIL>
+template <class Cfg, bool AR, bool BR, bool SHORT_TAIL>
 __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1, int Ktot,
                                           const float* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const float* const As0 = smem;
-  const float* const Bs0 = smem + 2 * BK * Cfg::LDA;
+  const float* const Bs0 = smem + 2 * Cfg::ABUF;
   __builtin_amdgcn_s_setprio(3);   // MFMA waves win issue arbitration over the loader waves of their SIMD
   __syncthreads();
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;
-    const float* const Ac = As0 + cur * (BK * Cfg::LDA);
-    const float* const Bc = Bs0 + cur * (BK * Cfg::LDB);
-    if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, 4>(Ac, Bc, acc, wm, wn, lane);
-    else mma_steps<Cfg, BK / 2>(Ac, Bc, acc, wm, wn, lane);
+    const float* const Ac = As0 + cur * Cfg::ABUF;
+    const float* const Bc = Bs0 + cur * Cfg::BBUF;
+    if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, AR, BR, 1>(Ac, Bc, acc, wm, wn, lane);
+    else mma_steps<Cfg, AR, BR, 4>(Ac, Bc, acc, wm, wn, lane);
     __syncthreads();
   }
 }
@@ -286,7 +301,7 @@ __device__ __forceinline__ bool gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg:
     loader_loop<Cfg>(al, bl, ks0, ks1, smem);
     return false;
   }
-  mfma_loop<Cfg, SHORT_TAIL>(acc, ks0, ks1, Ktot, smem);
+  mfma_loop<Cfg, AL::kTypeR, BL::kTypeR, SHORT_TAIL>(acc, ks0, ks1, Ktot, smem);
   return true;
 }
 

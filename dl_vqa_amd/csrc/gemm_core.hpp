@@ -3,26 +3,22 @@
 //   C[M,N] = sum_k A(m,k) * B(k,n)       exact fp32 (v_mfma_f32_32x32x2_f32)
 //
 // Design (see DESIGN.md "GEMM engine"):
-//   * 256-thread workgroup = 4 wave64; each wave owns a (WM x WN) sub-tile made of 32x32 MFMA
-//     tiles; accumulators stay in registers for the whole K loop.
-//   * Operands are staged through LDS in K-major images  As[BK][BM+1], Bs[BK][BN+1]:
-//     an MFMA A/B fragment is ONE dword per lane (lane l: row l&31, k = 2s + (l>>5)), so a
-//     fragment read is a stride-1 ds_read_b32 across 32 lanes: conflict free by construction.
-//     Fragment reads are software pipelined one k2-step ahead of the MFMAs that consume them.
-//   * Two kinds of operand loader fill those images from global memory, both with 16-byte
-//     per-lane loads, 8 lanes covering one 128-byte line:
-//       type R ("k-contiguous rows"):  thread -> (row r, k-chunk c); transposing LDS write
-//       type C ("reduction-major"):    thread -> (k-row kr, m-chunk c); straight LDS write
+//   * A workgroup = 4 (or 8) MFMA waves + 4 loader waves.  Each MFMA wave owns a (WM x WN) block of 32x32
+//     MFMA tiles; accumulators stay in registers for the whole K loop.  BK = 32 per barrier.
+//   * Operands are staged through LDS, double buffered, in an image chosen per operand type (LdsImage):
+//     16-byte stores for both types, 16-byte fragment reads for k-contiguous operands, stride-1 4-byte
+//     reads for reduction-major ones; all conflict-free.  The K order inside a K-step is permuted
+//     (k = 8t + 4h + q) so that one 16-byte read feeds four consecutive MFMAs.
+//   * Two kinds of operand loader fill those images from global memory, both with 16-byte per-lane loads,
+//     8 lanes covering one 128-byte line:
+//       type R ("k-contiguous rows"):  thread -> (row r, k-chunk c)
+//       type C ("reduction-major"):    thread -> (k-row kr, m-chunk c)
 //     Row addresses come from a functor, which is how implicit-im2col (conv forward), the
 //     max-pool-routed gradient (conv dgrad / wgrad) and plain matrices share one main loop.
 //   * A loader has two phases: issue(ks) computes addresses and issues UNCONDITIONAL 16-byte loads
 //     (out-of-range rows/chunks are clamped to a valid address) into a Raw register set; finish()
-//     applies masks / arg-max routing when the data is written to LDS.  Keeping every load
-//     unconditional and every use late is what lets the loads of K-step s+1 stay in flight under
-//     the MFMAs of step s (a predicated load makes hipcc branch and wait per load).
-//   * Register-staged double buffering: one barrier per K-step.  fp32 MFMA is 64 cycles per
-//     instruction per SIMD, so one K-step (BK = 32) is >= 1024 MFMA cycles per wave, which covers
-//     an HBM round trip.
+//     applies masks / arg-max routing when the data is written to LDS one or more K-steps later
+//     (a predicated load makes hipcc branch and wait per load).
 #pragma once
 #include "common.hpp"
 

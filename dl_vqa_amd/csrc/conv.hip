@@ -149,7 +149,8 @@ int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias
   // vs 72-73 %), whose loader is cheap; on dgrad the routing loader becomes the critical path with only one
   // loader wave per SIMD (51-62 % vs 64-70 %), so dgrad keeps 128-row tiles.  VQA_BIG_TILES=0/1 overrides.
   const char* bt = getenv("VQA_BIG_TILES");
-  const bool many_rows = (int64_t)4 * B * g.Hp * g.Wp >= 256 * 1024 && !(bt && bt[0] == '0');
+  const bool many_rows = bt && bt[0] == '1' ? true
+                       : ((int64_t)4 * B * g.Hp * g.Wp >= 256 * 1024 && !(bt && bt[0] == '0'));
   if (Co > 64) return many_rows ? launch_fwd<Cfg256x128>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream)
                                 : launch_fwd<Cfg128>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
   return launch_fwd<Cfg128x64>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
@@ -164,7 +165,7 @@ int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* 
   set_launch_tag(tag);
   ProfScope prof(VQA_K_CONV_DGRAD, (hipStream_t)stream);
   const char* bt = getenv("VQA_BIG_TILES");
-  const bool many_rows = (int64_t)B * H * W >= 256 * 1024 && bt && bt[0] == '1';   // see vqa_conv3x3_relu_pool_fwd
+  const bool many_rows = bt && bt[0] == '1';   // opt-in only, see vqa_conv3x3_relu_pool_fwd
   if (CiP > 64) return many_rows ? launch_dgrad<Cfg256x128>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
                                  : launch_dgrad<Cfg128>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
   return many_rows ? launch_dgrad<Cfg256x64>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)

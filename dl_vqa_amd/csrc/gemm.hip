@@ -145,7 +145,7 @@ static GemmPlan plan_gemm(int M, int N, int K) {
   // 256x128 tiles (8 MFMA waves, as the conv forward) measured 4-8 % SLOWER on the tall plain GEMMs
   // (v_conv fwd 1.29 vs 1.24 ms, dgrad 0.94 vs 0.87 ms): opt-in only (VQA_BIG_TILES=2)
   const char* bt = getenv("VQA_BIG_TILES");
-  if (p.big && splits == 1 && ((M + 255) / 256) * ((N + 127) / 128) >= 512 && bt && bt[0] == '2') p.big = 2;
+  if (p.big && splits == 1 && bt && bt[0] == '2') p.big = 2;
   const int bm = p.big == 2 ? 256 : (p.big ? 128 : 64), bn = p.big ? 128 : 64;
   p.tiles_m = (M + bm - 1) / bm;
   p.tiles_n = (N + bn - 1) / bn;

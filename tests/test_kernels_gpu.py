@@ -378,3 +378,18 @@ def test_conv0_dedicated_fwd_wgrad(B, Ci, H, W, Co):
     p2, a2 = ops.conv_fwd(ops.nchw_to_nhwc4(xd), wf, b.to(DEV), 1)
     torch.cuda.synchronize()
     assert float((p2 - pooled).abs().max()) < 1e-5 and float((a2 != amax).float().mean()) < 1e-3
+
+
+# ----------------------------------------------------------------------------- every tile configuration
+@pytest.mark.parametrize("big", ["0", "1", "2"])
+def test_tile_configurations_forced(big, monkeypatch):
+    """The 256-row / 8-MFMA-wave tile configurations are normally chosen by problem size (only the bench
+    shapes reach them); VQA_BIG_TILES forces each choice so that every compiled kernel is parity-checked:
+    0 = 128-row tiles everywhere, 1 = 256x128 / 256x64 conv forward + dgrad, 2 = 256x128 generic GEMM."""
+    monkeypatch.setenv("VQA_BIG_TILES", big)
+    test_conv_relu_pool_fwd_bwd(2, 58, 58, 64, 128, 1)
+    test_conv_relu_pool_fwd_bwd(1, 30, 30, 128, 256, 1)
+    test_conv_relu_pool_fwd_bwd(2, 40, 40, 64, 64, 1)
+    test_gemm_layouts(1030, 260, 3584, False, True)
+    test_gemm_layouts(1030, 260, 3584, False, False)
+    test_gemm_layouts(300, 200, 100, True, True)

@@ -45,6 +45,20 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   typename ConvFwdA<Cfg::NVA>::Params pa{x, g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
   typename PlainC<Cfg::NVB>::Params pb{wf, g.Co, g.Co, K};
   const int tiles_m = (4 * nWin + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.Co + Cfg::BN - 1) / Cfg::BN;
+  const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2), tiles = tiles_m * tiles_n;
+  const char* pt = getenv("VQA_PERSISTENT");
+  // Persistent tiles measured neutral to slower on the conv kernels (conv1 fwd 3.83 -> 3.81 ms, conv2 dgrad
+  // 3.65 -> 3.93 ms: their K loops are long and the second workgroup / MFMA wave of the SIMD already covers a
+  // tile's prologue and epilogue), so they are opt-in (VQA_PERSISTENT=1) and parity-tested that way.
+  const bool persistent = pt && pt[0] == '1';
+  if (persistent) {
+    auto pk = conv_fwd_persistent_kernel<Cfg>;
+    static bool done2 = false;
+    if (!done2) { int rc = set_smem(pk, Cfg::SMEM_BYTES, "attr(conv_fwd_p)"); if (rc) return rc; done2 = true; }
+    hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, bias,
+                       pooled, amax, g.Co, tiles_m, tiles_n, (K + BK - 1) / BK);
+    return check_hip(hipGetLastError(), "conv_fwd_persistent launch");
+  }
   auto kern = conv_fwd_kernel<Cfg>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_fwd)"); if (rc) return rc; done = true; }
@@ -60,6 +74,17 @@ static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, flo
   typename ConvDgradA<Cfg::NVA>::Params pa{dp, am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
   typename PlainC<Cfg::NVB>::Params pb{wd, g.CiP, g.CiP, K};
   const int tiles_m = (rows + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.CiP + Cfg::BN - 1) / Cfg::BN;
+  const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2), tiles = tiles_m * tiles_n;
+  const char* pt = getenv("VQA_PERSISTENT");
+  const bool persistent = pt && pt[0] == '1';   // see launch_fwd
+  if (persistent) {
+    auto pk = conv_dgrad_persistent_kernel<Cfg>;
+    static bool done2 = false;
+    if (!done2) { int rc = set_smem(pk, Cfg::SMEM_BYTES, "attr(conv_dgrad_p)"); if (rc) return rc; done2 = true; }
+    hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, dx,
+                       g.CiP, tiles_m, tiles_n, (K + BK - 1) / BK);
+    return check_hip(hipGetLastError(), "conv_dgrad_persistent launch");
+  }
   auto kern = conv_dgrad_kernel<Cfg>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_dgrad)"); if (rc) return rc; done = true; }

@@ -67,6 +67,78 @@ __device__ __forceinline__ float epi_apply(const EpiParams& e, float v, int row,
   return v;
 }
 
+template <class Cfg>
+__device__ __forceinline__ void gemm_epilogue(const EpiParams& pe, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
+                                              int wm, int wn, int lane) {
+  // Fused epilogue.  Per-column terms are loaded once per column; the row-group term (q' tiled over the
+  // image positions of a sample) needs row / rg_div: when a group is at least as tall as the tile
+  // (P = 676 >= 128) the tile spans at most two groups, so one division per workgroup replaces one per element.
+  const bool two_groups = pe.rg && pe.rg_div >= Cfg::BM;
+  const int g0 = pe.rg ? m0 / pe.rg_div : 0;
+  const int boundary = (g0 + 1) * pe.rg_div;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + acc_col<Cfg>(wn, j, lane);
+    const bool cok = col < pe.N;
+    float cb = 0.f;
+    if (cok && pe.bias1) cb += pe.bias1[col];
+    if (cok && pe.bias2) cb += pe.bias2[col];
+    float rg0 = 0.f, rg1 = 0.f;
+    if (two_groups && cok) {
+      rg0 = pe.rg[(int64_t)g0 * pe.rg_ld + col];
+      rg1 = boundary < pe.M ? pe.rg[(int64_t)(g0 + 1) * pe.rg_ld + col] : rg0;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
+        if (row < pe.M && cok) {
+          float v = acc[i][j][r];
+          const int64_t o = (int64_t)row * pe.ldc + col;
+          if (pe.aux) pe.aux[o] = v;
+          if (pe.rg) {
+            const float g = two_groups ? (row >= boundary ? rg1 : rg0)
+                                       : pe.rg[(int64_t)(row / pe.rg_div) * pe.rg_ld + col];
+            v = pe.rg_op ? v * g : v + g;
+          }
+          v += cb;
+          if (pe.relu) v = fmaxf(v, 0.f);
+          if (pe.accumulate) v += pe.C[o];
+          pe.C[o] = v;
+        }
+      }
+  }
+}
+
+// Persistent variant (no split-K, single Raw set): min(tiles, resident slots) workgroups walk the tiles.
+template <class Cfg, class AL, class BL>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_persistent_kernel(
+    typename AL::Params pa, typename BL::Params pb, EpiParams pe, int tiles_m, int tiles_n, int nk, int Ktot,
+    int order) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  auto origin = [&](int t, int& m0, int& n0) {
+    int mt, nt;
+    if (order == 1) { nt = t / tiles_m; mt = t - nt * tiles_m; } else { mt = t / tiles_n; nt = t - mt * tiles_n; }
+    m0 = mt * Cfg::BM; n0 = nt * Cfg::BN;
+  };
+  gemm_persistent<Cfg, AL, BL, false>(
+      xcd_swizzle(blockIdx.x, gridDim.x), gridDim.x, tiles_m * tiles_n, nk, Ktot, smem,
+      [&](int t, AL& al, BL& bl) {
+        int m0, n0;
+        origin(t, m0, n0);
+        al.init(pa, m0, loader_tid<Cfg>(), 0);
+        bl.init(pb, n0, loader_tid<Cfg>(), 0);
+      },
+      [&](int t, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+        int m0, n0;
+        origin(t, m0, n0);
+        gemm_epilogue<Cfg>(pe, acc, m0, n0, wm, wn, lane);
+      });
+}
+
 template <class Cfg, class AL, class BL>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_kernel(typename AL::Params pa, typename BL::Params pb,
                                                    EpiParams pe, int tiles_m, int tiles_n, int nk,
@@ -86,23 +158,21 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_kernel(type
   if (!gemm_mainloop<Cfg>(al, bl, acc, ks0, ks1, Ktot, smem)) return;
 
   float* slab = pe.slab ? pe.slab + (int64_t)split * pe.M * pe.N : nullptr;
+  if (slab) {
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+    for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j) {
-      const int col = n0 + acc_col<Cfg>(wn, j, lane);
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int col = n0 + acc_col<Cfg>(wn, j, lane);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
-        if (row < pe.M && col < pe.N) {
-          if (slab) slab[(int64_t)row * pe.N + col] = acc[i][j][r];
-          else {
-            if (pe.aux) pe.aux[(int64_t)row * pe.ldc + col] = acc[i][j][r];
-            pe.C[(int64_t)row * pe.ldc + col] = epi_apply(pe, acc[i][j][r], row, col);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
+          if (row < pe.M && col < pe.N) slab[(int64_t)row * pe.N + col] = acc[i][j][r];
         }
       }
-    }
+    return;
+  }
+  gemm_epilogue<Cfg>(pe, acc, m0, n0, wm, wn, lane);
 }
 
 __global__ void splitk_reduce_kernel(EpiParams pe, int splits) {
@@ -161,6 +231,30 @@ static GemmPlan plan_gemm(int M, int N, int K) {
 template <class Cfg, class AL, class BL>
 static int launch_gemm(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
                        const GemmPlan& p, int K, hipStream_t s) {
+  if constexpr (Cfg::PREFETCH == 1) {
+    // Persistent tiles pay when K is short (<= 16 K-steps: dispatch + prologue + epilogue are then a large
+    // share of a tile's life: v_conv forward 1.13 -> 1.04 ms, LSTM input GEMM 0.116 -> 0.105 ms); with long K
+    // the static tile striding loses more to imbalance than it saves (v_conv dgrad 0.82 -> 0.88 ms), so those
+    // keep one workgroup per tile and the hardware's dynamic dispatch.  VQA_PERSISTENT=0/1 forces the choice.
+    const char* pt = getenv("VQA_PERSISTENT");
+    const bool persistent = pt ? pt[0] == '1' : p.nk <= 16;
+    if (p.splits == 1 && persistent) {
+      static bool attr2 = false;
+      auto pk = gemm_persistent_kernel<Cfg, AL, BL>;
+      if (!attr2) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES),
+                           "hipFuncSetAttribute(gemm_persistent)");
+        if (rc) return rc;
+        attr2 = true;
+      }
+      const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2);
+      const int tiles = p.tiles_m * p.tiles_n;
+      hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, pe,
+                         p.tiles_m, p.tiles_n, p.nk, K, p.order);
+      return check_hip(hipGetLastError(), "gemm_persistent_kernel launch");
+    }
+  }
   static bool attr_done = false;
   auto kern = gemm_kernel<Cfg, AL, BL>;
   if (!attr_done) {

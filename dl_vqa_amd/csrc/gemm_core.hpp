@@ -301,6 +301,82 @@ __device__ __forceinline__ bool gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg:
   return true;
 }
 
+// ---------------------------------------------------------------- persistent tiles
+// A workgroup walks the tiles  first, first + stride, ...  (< ntiles), every tile running the SAME K-steps
+// [0, nk).  The loader waves treat the tiles as one flat sequence of K-steps: while the MFMA waves run the
+// epilogue of tile t, the first K-step of tile t+1 is already in LDS and its second in registers, and no
+// workgroup is re-dispatched between tiles (a 128x128 tile with K = 256 lives only ~28 us, so dispatch +
+// prologue + epilogue per tile were a large part of it).  Requires Cfg::PREFETCH == 1: the loader
+// functor's state is re-initialised right before the first issue() of a new tile, after the last
+// finish() of the old one.
+//   init_tile(tile, AL&, BL&)   : (re)initialise both loaders for a tile
+//   epilogue(tile, acc)         : MFMA waves only, no barriers inside
+template <class Cfg, class AL, class BL, bool SHORT_TAIL, class InitTile, class Epilogue>
+__device__ __forceinline__ void gemm_persistent(int first, int stride, int ntiles, int nk, int Ktot, float* smem,
+                                                InitTile&& init_tile, Epilogue&& epilogue) {
+  static_assert(Cfg::PREFETCH == 1, "persistent tiles need a single Raw register set");
+  if (first >= ntiles) return;
+  const int my_tiles = (ntiles - first + stride - 1) / stride;
+  const int total = my_tiles * nk;
+  if (is_loader_wave<Cfg>()) {
+    const int ltid = loader_tid<Cfg>();
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * Cfg::ABUF;
+    AL al; BL bl;
+    typename AL::Raw rawA;
+    typename BL::Raw rawB;
+    int tile = first, ks = 0;            // the K-step the next issue() fetches
+    init_tile(tile, al, bl);
+    auto next = [&]() {                  // issue K-step (tile, ks) and advance the cursor across tile seams
+      if (ks == nk) {
+        ks = 0;
+        if (tile + stride < ntiles) tile += stride;     // past the last tile: harmless refetch, never read
+        init_tile(tile, al, bl);
+      }
+      al.issue(ks, rawA);
+      bl.issue(ks, rawB);
+      ++ks;
+    };
+    next();
+    stage_store_one<Cfg, AL, true>(al, rawA, As0, ltid);
+    stage_store_one<Cfg, BL, false>(bl, rawB, Bs0, ltid);
+    next();
+    __syncthreads();
+    for (int s = 0; s < total; ++s) {
+      const int nxt = (s & 1) ^ 1;
+      stage_store_one<Cfg, AL, true>(al, rawA, As0 + nxt * Cfg::ABUF, ltid);
+      stage_store_one<Cfg, BL, false>(bl, rawB, Bs0 + nxt * Cfg::BBUF, ltid);
+      next();
+      __syncthreads();
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const float* const As0 = smem;
+  const float* const Bs0 = smem + 2 * Cfg::ABUF;
+  __builtin_amdgcn_s_setprio(3);
+  __syncthreads();
+  int s = 0;
+  for (int tile = first; tile < ntiles; tile += stride) {
+    f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int ks = 0; ks < nk; ++ks, ++s) {
+      const float* const Ac = As0 + (s & 1) * Cfg::ABUF;
+      const float* const Bc = Bs0 + (s & 1) * Cfg::BBUF;
+      if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, AL::kTypeR, BL::kTypeR, 1>(Ac, Bc, acc, wm, wn, lane);
+      else mma_steps<Cfg, AL::kTypeR, BL::kTypeR, 4>(Ac, Bc, acc, wm, wn, lane);
+      __syncthreads();
+    }
+    epilogue(tile, acc);
+  }
+}
+
 template <class Cfg>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
 #pragma unroll

@@ -381,6 +381,17 @@ def test_conv0_dedicated_fwd_wgrad(B, Ci, H, W, Co):
 
 
 # ----------------------------------------------------------------------------- every tile configuration
+@pytest.mark.parametrize("persistent", ["0", "1"])
+def test_persistent_tiles_forced(persistent, monkeypatch):
+    """VQA_PERSISTENT forces the persistent-tile kernels (normally chosen for short-K GEMMs only) on or off."""
+    monkeypatch.setenv("VQA_PERSISTENT", persistent)
+    test_conv_relu_pool_fwd_bwd(2, 58, 58, 64, 128, 1)
+    test_conv_relu_pool_fwd_bwd(3, 31, 29, 3, 8, 1)
+    test_gemm_layouts(1030, 260, 3584, False, True)
+    test_gemm_layouts(300, 200, 100, False, False)
+    test_gemm_epilogue_bias_rowgroup_relu_accumulate()
+
+
 @pytest.mark.parametrize("big", ["0", "1", "2"])
 def test_tile_configurations_forced(big, monkeypatch):
     """The 256-row / 8-MFMA-wave tile configurations are normally chosen by problem size (only the bench

@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvqa_hip.so")
+LIB_PATH = os.environ.get("VQA_LIB", os.path.join(_HERE, "libvqa_hip.so"))   # VQA_LIB: diagnostic builds only
 
 f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 u8p = C.c_void_p

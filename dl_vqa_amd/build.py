@@ -28,17 +28,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force: bool = False, verbose: bool = True) -> str:
-    """Compile every .hip source for gfx950 and link the shared library. Returns its path."""
+def build_library(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
+    """Compile every .hip source for gfx950 and link the shared library. Returns its path.
+    diag=True builds libvqa_hip_diag.so with -DVQA_DIAG (in-kernel s_memtime stamps; tools/ only)."""
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     jobs = []
+    lib = LIB.replace(".so", "_diag.so") if diag else LIB
+    flags = FLAGS + (["-DVQA_DIAG"] if diag else [])
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", "_diag.o" if diag else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc()] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([_hipcc()] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -50,10 +53,10 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    print(build_library(force="--force" in sys.argv, diag="--diag" in sys.argv))

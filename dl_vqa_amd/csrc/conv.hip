@@ -242,3 +242,15 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
 }
 
 }  // extern "C"
+
+#ifdef VQA_DIAG
+// diagnostic build only: read-and-reset the s_memtime sums of the conv kernels (this translation unit)
+extern "C" int vqa_diag_read(unsigned long long* out8) {
+  unsigned long long z[4] = {0, 0, 0, 0};
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(vqa::vqa_diag_buf), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out8 + 4, HIP_SYMBOL(vqa::vqa_diag_ld), sizeof(z)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(vqa::vqa_diag_ld), z, sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(vqa::vqa_diag_buf), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -26,6 +26,15 @@ namespace vqa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef VQA_DIAG
+// Diagnostic build only (python -m dl_vqa_amd.build --diag -> libvqa_hip_diag.so, never loaded by default):
+// MFMA waves stamp s_memtime around the MFMA block and around the barrier of every K-step.
+// [0] cycles in mma_steps, [1] cycles waiting at the K-step barrier, [2] wave count, [3] total cycles
+static __device__ unsigned long long vqa_diag_buf[4];
+// loader waves: [0] finish+ds_write (incl. waiting for the loads), [1] issue, [2] barrier wait, [3] waves
+static __device__ unsigned long long vqa_diag_ld[4];
+#endif
+
 constexpr int BK = 32;  // K-step depth (floats): 8 lanes x 16 B = one 128-B line per row
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
@@ -252,19 +261,42 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
     bl.issue(ks0 + 1 + d, rawB[d]);
   }
   __syncthreads();
+#ifdef VQA_DIAG
+  unsigned long long t_st = 0, t_is = 0, t_ba = 0;
+#endif
   for (int ks = ks0; ks < ks1; ks += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       if (ks + d < ks1) {                                 // block-uniform; one barrier per K-step, as the MFMA role
         const int nxt = ((ks + d - ks0) & 1) ^ 1;
+#ifdef VQA_DIAG
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * Cfg::ABUF, ltid);
+        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * Cfg::BBUF, ltid);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        al.issue(ks + d + 1 + D, rawA[d]);
+        bl.issue(ks + d + 1 + D, rawB[d]);
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        t_st += t1 - t0; t_is += t2 - t1; t_ba += t3 - t2;
+#else
         stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * Cfg::ABUF, ltid);
         al.issue(ks + d + 1 + D, rawA[d]);
         stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * Cfg::BBUF, ltid);
         bl.issue(ks + d + 1 + D, rawB[d]);
         __syncthreads();
+#endif
       }
     }
   }
+#ifdef VQA_DIAG
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&vqa_diag_ld[0], t_st); atomicAdd(&vqa_diag_ld[1], t_is); atomicAdd(&vqa_diag_ld[2], t_ba);
+    atomicAdd(&vqa_diag_ld[3], 1ULL);
+  }
+#endif
 }
 
 // MFMA role.  SHORT_TAIL (conv0 forward, K = 36 = 32 + 4): the last K-step runs 4 k2-steps instead of 16.
@@ -276,15 +308,35 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
   const float* const As0 = smem;
   const float* const Bs0 = smem + 2 * Cfg::ABUF;
   __builtin_amdgcn_s_setprio(3);   // MFMA waves win issue arbitration over the loader waves of their SIMD
+#ifdef VQA_DIAG
+  unsigned long long t_mma = 0, t_bar = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;
     const float* const Ac = As0 + cur * Cfg::ABUF;
     const float* const Bc = Bs0 + cur * Cfg::BBUF;
+#ifdef VQA_DIAG
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
     if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, AR, BR, 1>(Ac, Bc, acc, wm, wn, lane);
     else mma_steps<Cfg, AR, BR, 4>(Ac, Bc, acc, wm, wn, lane);
+#ifdef VQA_DIAG
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef VQA_DIAG
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    t_mma += t1 - t0; t_bar += t2 - t1;
+#endif
   }
+#ifdef VQA_DIAG
+  if (lane == 0) {
+    atomicAdd(&vqa_diag_buf[0], t_mma); atomicAdd(&vqa_diag_buf[1], t_bar); atomicAdd(&vqa_diag_buf[2], 1ULL);
+    atomicAdd(&vqa_diag_buf[3], __builtin_amdgcn_s_memtime() - t_begin);
+  }
+#endif
 }
 
 // Whole contraction over K-steps [ks0, ks1) (ks1 > ks0).  Returns true for MFMA waves (which hold the

@@ -31,6 +31,9 @@ using Cfg128x64 = TileCfg<128, 64, 2, 2>;
 using Cfg256x128 = TileCfg<256, 128, 4, 2>;   // 8 MFMA waves (64x64 each) + 4 loader waves, one workgroup per CU
 using Cfg256x64 = TileCfg<256, 64, 4, 2>;     // 8 MFMA waves (64x32 each)
 using Cfg64 = TileCfg<64, 64, 2, 2>;
+// the same tiles with 8 loader waves (1024 threads): two loader waves per SIMD for loader-bound K loops
+using Cfg256x128L8 = TileCfg<256, 128, 4, 2, 8>;
+using Cfg256x64L8 = TileCfg<256, 64, 4, 2, 8>;
 
 template <class K>
 static int set_smem(K kern, int bytes, const char* what) {
@@ -42,8 +45,8 @@ template <class Cfg>
 static int launch_fwd(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* amax,
                       const ConvGeom& g, hipStream_t s) {
   const int nWin = g.B * g.Hp * g.Wp, K = 9 * g.CiP;
-  typename ConvFwdA<Cfg::NVA>::Params pa{x, g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
-  typename PlainC<Cfg::NVB>::Params pb{wf, g.Co, g.Co, K};
+  typename ConvFwdA<Cfg::NVA, Cfg::LT>::Params pa{x, g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
+  typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wf, g.Co, g.Co, K};
   const int tiles_m = (4 * nWin + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.Co + Cfg::BN - 1) / Cfg::BN;
   const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2), tiles = tiles_m * tiles_n;
   const char* pt = getenv("VQA_PERSISTENT");
@@ -52,7 +55,7 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   // tile's prologue and epilogue), so they are opt-in (VQA_PERSISTENT=1) and parity-tested that way.
   const bool persistent = pt && pt[0] == '1';
   if (persistent) {
-    auto pk = conv_fwd_persistent_kernel<Cfg>;
+    auto pk = conv_fwd_persistent_kernel<typename Cfg::Persistent>;
     static bool done2 = false;
     if (!done2) { int rc = set_smem(pk, Cfg::SMEM_BYTES, "attr(conv_fwd_p)"); if (rc) return rc; done2 = true; }
     hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, bias,
@@ -71,14 +74,14 @@ template <class Cfg>
 static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, float* dx, const ConvGeom& g,
                         hipStream_t s) {
   const int rows = g.B * g.H * g.W, K = 9 * g.Co;
-  typename ConvDgradA<Cfg::NVA>::Params pa{dp, am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
-  typename PlainC<Cfg::NVB>::Params pb{wd, g.CiP, g.CiP, K};
+  typename ConvDgradA<Cfg::NVA, Cfg::LT>::Params pa{dp, am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
+  typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wd, g.CiP, g.CiP, K};
   const int tiles_m = (rows + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.CiP + Cfg::BN - 1) / Cfg::BN;
   const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2), tiles = tiles_m * tiles_n;
   const char* pt = getenv("VQA_PERSISTENT");
   const bool persistent = pt && pt[0] == '1';   // see launch_fwd
   if (persistent) {
-    auto pk = conv_dgrad_persistent_kernel<Cfg>;
+    auto pk = conv_dgrad_persistent_kernel<typename Cfg::Persistent>;
     static bool done2 = false;
     if (!done2) { int rc = set_smem(pk, Cfg::SMEM_BYTES, "attr(conv_dgrad_p)"); if (rc) return rc; done2 = true; }
     hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, dx,
@@ -119,8 +122,8 @@ template <class Cfg>
 static int launch_wgrad(const float* x, const float* dp, const uint8_t* am, float* slab, float* bias_slab,
                         const ConvGeom& g, const WgradPlan& p, hipStream_t s) {
   WgradGeom wg{g.H, g.W, g.CiP, g.Hp, g.Wp, g.Co, g.stride, p.Mtot};
-  typename WgradA<Cfg::NVA>::Params pa{x, wg, p.KI};
-  typename WgradB<Cfg::NVB>::Params pb{dp, am, wg};
+  typename WgradA<Cfg::NVA, Cfg::LT>::Params pa{x, wg, p.KI};
+  typename WgradB<Cfg::NVB, Cfg::LT>::Params pb{dp, am, wg};
   auto kern = conv_wgrad_kernel<Cfg>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_wgrad)"); if (rc) return rc; done = true; }
@@ -136,6 +139,9 @@ static int check_geom(const char* fn, const ConvGeom& g) {
   VQA_REQUIRE(g.stride == 1 || g.stride == 2, "%s: stride %d unsupported (1 or 2)", fn, g.stride);
   VQA_REQUIRE(g.Hp > 0 && g.Wp > 0, "%s: image too small for conv+pool", fn);
   VQA_REQUIRE((int64_t)g.B * g.H * g.W < (1LL << 31) / 4, "%s: too many pixels for 32-bit row indices", fn);
+  // the loaders address each tensor with 32-bit byte offsets from its first element
+  VQA_REQUIRE((int64_t)g.B * g.H * g.W * g.CiP * 4 < (1LL << 32) - 4096 && (int64_t)g.B * g.Hp * g.Wp * g.Co * 4 < (1LL << 32) - 4096,
+              "%s: a tensor of this layer reaches 4 GiB (B=%d): split the batch", fn, g.B);
   return VQA_OK;
 }
 
@@ -176,6 +182,7 @@ int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias
   const char* bt = getenv("VQA_BIG_TILES");
   const bool many_rows = bt && bt[0] == '1' ? true
                        : ((int64_t)4 * B * g.Hp * g.Wp >= 256 * 1024 && !(bt && bt[0] == '0'));
+  if (bt && bt[0] == '3' && Co > 64) return launch_fwd<Cfg256x128L8>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
   if (Co > 64) return many_rows ? launch_fwd<Cfg256x128>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream)
                                 : launch_fwd<Cfg128>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
   return launch_fwd<Cfg128x64>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
@@ -191,6 +198,9 @@ int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* 
   ProfScope prof(VQA_K_CONV_DGRAD, (hipStream_t)stream);
   const char* bt = getenv("VQA_BIG_TILES");
   const bool many_rows = bt && bt[0] == '1';   // opt-in only, see vqa_conv3x3_relu_pool_fwd
+  if (bt && bt[0] == '3')
+    return CiP > 64 ? launch_dgrad<Cfg256x128L8>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
+                    : launch_dgrad<Cfg256x64L8>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
   if (CiP > 64) return many_rows ? launch_dgrad<Cfg256x128>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
                                  : launch_dgrad<Cfg128>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
   return many_rows ? launch_dgrad<Cfg256x64>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)

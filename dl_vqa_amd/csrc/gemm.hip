@@ -231,7 +231,7 @@ static GemmPlan plan_gemm(int M, int N, int K) {
 template <class Cfg, class AL, class BL>
 static int launch_gemm(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
                        const GemmPlan& p, int K, hipStream_t s) {
-  if constexpr (Cfg::PREFETCH == 1) {
+  if constexpr (Cfg::BM * Cfg::BN > 64 * 64) {
     // Persistent tiles pay when K is short (<= 16 K-steps: dispatch + prologue + epilogue are then a large
     // share of a tile's life: v_conv forward 1.13 -> 1.04 ms, LSTM input GEMM 0.116 -> 0.105 ms); with long K
     // the static tile striding loses more to imbalance than it saves (v_conv dgrad 0.82 -> 0.88 ms), so those
@@ -240,7 +240,7 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
     const bool persistent = pt ? pt[0] == '1' : p.nk <= 16;
     if (p.splits == 1 && persistent) {
       static bool attr2 = false;
-      auto pk = gemm_persistent_kernel<Cfg, AL, BL>;
+      auto pk = gemm_persistent_kernel<typename Cfg::Persistent, AL, BL>;
       if (!attr2) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES),
@@ -277,8 +277,8 @@ using Cfg64 = TileCfg<64, 64, 2, 2>;
 template <class Cfg>
 static int dispatch_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
                          const EpiParams& pe, const GemmPlan& p, int M, int N, int K, hipStream_t s) {
-  using AR = PlainR<Cfg::NVA>; using AC = PlainC<Cfg::NVA>;
-  using BR = PlainR<Cfg::NVB>; using BC = PlainC<Cfg::NVB>;
+  using AR = PlainR<Cfg::NVA, Cfg::LT>; using AC = PlainC<Cfg::NVA, Cfg::LT>;
+  using BR = PlainR<Cfg::NVB, Cfg::LT>; using BC = PlainC<Cfg::NVB, Cfg::LT>;
   if (!transA && transB) return launch_gemm<Cfg, AR, BR>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
   if (!transA && !transB) return launch_gemm<Cfg, AR, BC>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
   if (transA && transB) return launch_gemm<Cfg, AC, BR>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
@@ -338,6 +338,8 @@ int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ld
   VQA_REQUIRE(M > 0 && N > 0 && K > 0, "vqa_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   VQA_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && lda % 4 == 0 && ldb % 4 == 0,
               "vqa_gemm: A/B must be 16-byte aligned with leading dimensions multiple of 4 (lda=%lld ldb=%lld)",
+              (long long)lda, (long long)ldb);
+  VQA_REQUIRE(lda < (1 << 21) && ldb < (1 << 21), "vqa_gemm: leading dimensions must be below 2^21 (lda=%lld ldb=%lld)",
               (long long)lda, (long long)ldb);
   VQA_REQUIRE(!rowgroup || rg_div > 0, "vqa_gemm: rg_div must be positive");
   hipStream_t s = (hipStream_t)stream;

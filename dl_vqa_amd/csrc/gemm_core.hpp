@@ -35,17 +35,27 @@ static __device__ unsigned long long vqa_diag_buf[4];
 static __device__ unsigned long long vqa_diag_ld[4];
 #endif
 
+// wave priorities of the two roles (s_setprio), overridable for experiments
+#ifndef VQA_PRIO_MFMA
+#define VQA_PRIO_MFMA 3
+#endif
+#ifndef VQA_PRIO_LOADER
+#define VQA_PRIO_LOADER 0
+#endif
+
 constexpr int BK = 32;  // K-step depth (floats): 8 lanes x 16 B = one 128-B line per row
 
-template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int LOADER_WAVES_ = 4, int PREFETCH_ = 0>
 struct TileCfg {
+  static_assert(LOADER_WAVES_ == 4 || LOADER_WAVES_ == 8, "4 or 8 loader waves");
+  static constexpr int LT = 64 * LOADER_WAVES_;            // loader threads
   static_assert(WAVES_M_ * WAVES_N_ == 4 || WAVES_M_ * WAVES_N_ == 8, "4 or 8 MFMA waves per workgroup");
   static constexpr int BM = BM_, BN = BN_;
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   static constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1 && WM % 32 == 0 && WN % 32 == 0, "wave tile = 32x32 MFMA tiles");
-  static constexpr int NVA = BM / 32, NVB = BN / 32;  // float4 per thread per K-step
+  static constexpr int NVA = BM * 8 / LT, NVB = BN * 8 / LT;  // float4 per loader thread per K-step
   // One LDS buffer per operand per stage.  Its image depends on the operand's loader type (LdsImage):
   // both forms fit in 36 floats per row/column of the tile.
   static constexpr int ABUF = 36 * BM, BBUF = 36 * BN;      // floats
@@ -55,12 +65,15 @@ struct TileCfg {
   // two 512-thread workgroups per CU (4 waves/SIMD, <= 128 VGPRs) up to 128x128, one above that
   static constexpr int NMFMA = WAVES_M * WAVES_N;          // MFMA waves (threads 0 .. 64*NMFMA-1)
   static constexpr int MFMA_THREADS = 64 * NMFMA;
-  static constexpr int THREADS = MFMA_THREADS + 256;       // + 4 loader waves
+  static constexpr int THREADS = MFMA_THREADS + LT;        // + the loader waves
   static constexpr int MIN_WAVES = (THREADS / 256) * ((SMEM_BYTES > 80 * 1024) ? 1 : 2);
+  static_assert(NVA >= 1 && NVB >= 1, "tile too small for this many loader threads");
   // K-steps of global loads a loader thread keeps in flight (register ring).  A 64x64 tile's K-step is
   // only 1024 MFMA cycles (~0.45 us), shorter than an L2 round trip, so it needs 3 steps of run-ahead;
   // the big tiles' K-steps (>= 4096 cycles) cover the latency with one and have no registers to spare.
-  static constexpr int PREFETCH = (BM * BN <= 64 * 64) ? 3 : 1;
+  static constexpr int PREFETCH = PREFETCH_ ? PREFETCH_ : (BM * BN <= 64 * 64) ? 3 : (BM * BN <= 128 * 128) ? 2 : 1;
+  // the persistent-tile loop re-initialises its loaders at tile seams and needs a single Raw set
+  using Persistent = TileCfg<BM_, BN_, WAVES_M_, WAVES_N_, LOADER_WAVES_, 1>;
 };
 
 // LDS images.  An fp32 MFMA fragment is one dword per lane and the K order inside a K-step is free as
@@ -74,21 +87,29 @@ struct TileCfg {
 constexpr int LDS_RS = 36;
 template <int TILE> struct LdsImage { static constexpr int CS = TILE + 4; };
 
-// Thread -> staging coordinates, common to both loader types.
-//   r32 = tid >> 3 (0..31), c8 = tid & 7 (0..7)
-// type R: rows r32 + 32*p (p < TILE/32), k-chunk c8 (k = 4*c8 .. 4*c8+3)
-// type C: k-row r32, chunks c8 + 8*p (tile elements 4*(c8+8p) .. +3)
-template <int TILE, int NV>
-__device__ __forceinline__ void lds_store_R(float* s, const float4 (&r)[NV], int tid) {
-  const int r32 = tid >> 3, c8 = tid & 7;
+// Loader thread -> staging coordinates, for LT = 256 or 512 loader threads (8 lanes = one 128-B line).
+//   type R: rows (ltid >> 3) + (LT/8)*p, k-chunk ltid & 7 (k = 4*chunk .. +3)
+//   type C: k-row (ltid >> 3) & 31, tile chunks (ltid & 7) + 8*(ltid >> 8) + (LT/32)*p  (elements 4*chunk .. +3)
+template <int LT>
+struct StageMap {
+  static constexpr int RP = LT / 8;      // type R rows per pass
+  static constexpr int CP = LT / 32;     // type C chunks per pass
+  static __device__ __forceinline__ int r_row(int ltid, int p) { return (ltid >> 3) + RP * p; }
+  static __device__ __forceinline__ int r_chunk(int ltid) { return ltid & 7; }
+  static __device__ __forceinline__ int c_krow(int ltid) { return (ltid >> 3) & 31; }
+  static __device__ __forceinline__ int c_chunk(int ltid, int p) { return (ltid & 7) + 8 * (ltid >> 8) + CP * p; }
+};
+template <int TILE, int NV, int LT>
+__device__ __forceinline__ void lds_store_R(float* s, const float4 (&r)[NV], int ltid) {
 #pragma unroll
-  for (int p = 0; p < NV; ++p) *reinterpret_cast<float4*>(s + (r32 + 32 * p) * LDS_RS + 4 * c8) = r[p];
+  for (int p = 0; p < NV; ++p)
+    *reinterpret_cast<float4*>(s + StageMap<LT>::r_row(ltid, p) * LDS_RS + 4 * StageMap<LT>::r_chunk(ltid)) = r[p];
 }
-template <int TILE, int NV>
-__device__ __forceinline__ void lds_store_C(float* s, const float4 (&r)[NV], int tid) {
-  const int r32 = tid >> 3, c8 = tid & 7;
+template <int TILE, int NV, int LT>
+__device__ __forceinline__ void lds_store_C(float* s, const float4 (&r)[NV], int ltid) {
 #pragma unroll
-  for (int p = 0; p < NV; ++p) *reinterpret_cast<float4*>(s + r32 * LdsImage<TILE>::CS + 4 * (c8 + 8 * p)) = r[p];
+  for (int p = 0; p < NV; ++p)
+    *reinterpret_cast<float4*>(s + StageMap<LT>::c_krow(ltid) * LdsImage<TILE>::CS + 4 * StageMap<LT>::c_chunk(ltid, p)) = r[p];
 }
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -102,64 +123,109 @@ __device__ __forceinline__ float4 mask4(float4 v, bool on, int e0, int len) {
   return v;
 }
 
+// ---------------------------------------------------------------- buffer addressing
+// Loader waves share their SIMD with MFMA waves, and on gfx950 every VALU instruction a loader wave issues
+// takes the slot of an MFMA pass (measured: kernel time ~= MFMA-only time + loader VALU time, whatever the
+// wave priorities), while SALU, VMEM and LDS instructions issue beside the MFMA stream for free.  So the
+// loaders keep their per-K-step work off the VALU: a thread's offsets inside the tile are computed once
+// (init), the K-step advance is a scalar add on the buffer resource's base address, and rows / columns
+// past the end are lanes whose offset is BUF_OOB: the hardware range check returns zeros for them, which
+// replaces both the address clamp and the v_cndmask masking of a plain global load.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t BUF_OOB = 0xfffffff0u;   // >= any num_records: the lane reads zeros, no memory access
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, uint32_t bytes = 0xffffff00u) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ uint32_t buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff = 0) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+
 // ---------------------------------------------------------------- plain matrix loaders
-// Both require ld >= roundup4(row length): a 16-byte load never leaves the row's allocation.
+// Both require ld >= roundup4(row length) (a 16-byte load never leaves the row's allocation) and
+// 256 * ld * 4 < 2^32 (offsets inside a tile are 32-bit; the tile origin is a 64-bit scalar).
+// Loader concept:  init(params, tile origin, loader thread, first K-step)
+//                  issue(ks, Raw&)   global loads of K-step ks into registers (any ks >= first; past the
+//                                    end of K every lane is out of range and reads zeros)
+//                  finish(Raw, out)  the NV 16-byte chunks as they go to LDS
 // Type R over a row-major matrix X[rows][K]: used for A=[M][K] and B=[N][K].
-template <int NV>
+template <int NV, int LT = 256>
 struct PlainR {
   struct Params { const float* p; int64_t ld; int rows; int K; };
-  struct Raw { float4 v[NV]; int k; };
+  struct Raw { float4 v[NV]; int rem; };   // rem = K - ks*BK (uniform): < BK on the tail step, <= 0 past the end
   static constexpr bool kTypeR = true;
-  const float* rowp[NV];
-  bool ok[NV];
+  const float* base;      // first row of the tile (uniform)
+  uint32_t voff[NV];      // byte offset of the thread's chunk from base; BUF_OOB for rows past the end
   int K, c4;
   __device__ __forceinline__ void init(const Params& q, int row0, int tid, int /*ks0*/) {
-    K = q.K; c4 = 4 * (tid & 7);
+    K = q.K; c4 = 4 * StageMap<LT>::r_chunk(tid);
+    base = q.p + (int64_t)row0 * q.ld;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
-      const int r = row0 + (tid >> 3) + 32 * p;
-      ok[p] = r < q.rows;
-      rowp[p] = q.p + (int64_t)(ok[p] ? r : 0) * q.ld;
+      const int rl = StageMap<LT>::r_row(tid, p);
+      voff[p] = row0 + rl < q.rows ? (uint32_t)(rl * (int)q.ld + c4) * 4u : BUF_OOB;
     }
   }
   __device__ __forceinline__ void issue(int ks, Raw& r) {
-    const int k = ks * BK + c4;
-    const int kc = k < K ? k : 0;
-    r.k = k;
+    r.rem = K - ks * BK;
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(base + (int64_t)ks * BK);
+    if (r.rem >= BK) {
 #pragma unroll
-    for (int p = 0; p < NV; ++p) r.v[p] = *reinterpret_cast<const float4*>(rowp[p] + kc);
+      for (int p = 0; p < NV; ++p) r.v[p] = buf_load16(rs, voff[p]);
+    } else {          // tail K-step (or past the end): chunks at or beyond K read zeros
+#pragma unroll
+      for (int p = 0; p < NV; ++p) r.v[p] = buf_load16(rs, c4 < r.rem ? voff[p] : BUF_OOB);
+    }
   }
   __device__ __forceinline__ void finish(const Raw& r, float4 (&o)[NV]) const {
+    if (r.rem >= BK) {
 #pragma unroll
-    for (int p = 0; p < NV; ++p) o[p] = mask4(r.v[p], ok[p], r.k, K);
+      for (int p = 0; p < NV; ++p) o[p] = r.v[p];
+    } else {          // a chunk straddling K (K % 4 != 0) keeps only its elements below K
+#pragma unroll
+      for (int p = 0; p < NV; ++p) o[p] = mask4(r.v[p], true, c4, r.rem);
+    }
   }
 };
 
-// Type C over a row-major matrix X[K][cols] (reduction index is the slow one).
-template <int NV>
+// Type C over a row-major matrix X[K][cols] (reduction index is the slow one).  Columns at or beyond
+// `cols` inside a straddling chunk are not masked: they only reach accumulator rows / columns that no
+// epilogue stores.
+template <int NV, int LT = 256>
 struct PlainC {
   struct Params { const float* p; int64_t ld; int cols; int K; };
-  struct Raw { float4 v[NV]; bool kok; };
+  struct Raw { float4 v[NV]; };
   static constexpr bool kTypeR = false;
-  const float* base;
+  const float* base;      // column col0 of row 0 (uniform)
   int64_t ld;
-  int K, cols, col0, kr;
-  __device__ __forceinline__ void init(const Params& q, int col0_, int tid, int /*ks0*/) {
-    base = q.p; ld = q.ld; K = q.K; cols = q.cols; col0 = col0_ + 4 * (tid & 7); kr = tid >> 3;
-  }
-  __device__ __forceinline__ void issue(int ks, Raw& r) {
-    const int k = ks * BK + kr;
-    r.kok = k < K;
-    const float* row = base + (int64_t)(r.kok ? k : 0) * ld;
+  uint32_t voff[NV];
+  int K, kr;
+  __device__ __forceinline__ void init(const Params& q, int col0, int tid, int /*ks0*/) {
+    ld = q.ld; K = q.K; kr = StageMap<LT>::c_krow(tid);
+    base = q.p + col0;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
-      const int c = col0 + 32 * p;
-      r.v[p] = *reinterpret_cast<const float4*>(row + (c < cols ? c : 0));
+      const int cl = 4 * StageMap<LT>::c_chunk(tid, p);
+      voff[p] = col0 + cl < q.cols ? (uint32_t)(kr * (int)q.ld + cl) * 4u : BUF_OOB;
+    }
+  }
+  __device__ __forceinline__ void issue(int ks, Raw& r) {
+    const int rem = K - ks * BK;
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(base + (int64_t)ks * BK * ld);
+    if (rem >= BK) {
+#pragma unroll
+      for (int p = 0; p < NV; ++p) r.v[p] = buf_load16(rs, voff[p]);
+    } else {
+#pragma unroll
+      for (int p = 0; p < NV; ++p) r.v[p] = buf_load16(rs, kr < rem ? voff[p] : BUF_OOB);
     }
   }
   __device__ __forceinline__ void finish(const Raw& r, float4 (&o)[NV]) const {
 #pragma unroll
-    for (int p = 0; p < NV; ++p) o[p] = mask4(r.v[p], r.kok, col0 + 32 * p, cols);
+    for (int p = 0; p < NV; ++p) o[p] = r.v[p];
   }
 };
 
@@ -232,13 +298,13 @@ __device__ __forceinline__ void stage_store_one(const L& ld, const typename L::R
   constexpr int TILE = IS_A ? Cfg::BM : Cfg::BN;
   float4 r[NV];
   ld.finish(raw, r);
-  if (L::kTypeR) lds_store_R<TILE, NV>(dst, r, ltid); else lds_store_C<TILE, NV>(dst, r, ltid);
+  if (L::kTypeR) lds_store_R<TILE, NV, Cfg::LT>(dst, r, ltid); else lds_store_C<TILE, NV, Cfg::LT>(dst, r, ltid);
 }
 
 template <class Cfg> __device__ __forceinline__ bool is_loader_wave() { return threadIdx.x >= Cfg::MFMA_THREADS; }
 // staging thread id (0..255): the loader waves are the last four of the workgroup; MFMA waves get a
 // harmless in-range value (they construct loaders but never use them)
-template <class Cfg> __device__ __forceinline__ int loader_tid() { return (threadIdx.x - Cfg::MFMA_THREADS) & 255; }
+template <class Cfg> __device__ __forceinline__ int loader_tid() { return (threadIdx.x - Cfg::MFMA_THREADS) & (Cfg::LT - 1); }
 
 // Loader role: K-steps [ks0, ks1).  Loaders tolerate issue() past the end (addresses clamped, data masked).
 // Ring of D = Cfg::PREFETCH Raw register sets: at K-step ks the tile of step ks+1 is written to the other
@@ -251,6 +317,7 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
   float* const Bs0 = smem + 2 * Cfg::ABUF;
   typename AL::Raw rawA[D];
   typename BL::Raw rawB[D];
+  if (VQA_PRIO_LOADER) __builtin_amdgcn_s_setprio(VQA_PRIO_LOADER);
   al.issue(ks0, rawA[0]);
   bl.issue(ks0, rawB[0]);
   stage_store_one<Cfg, AL, true>(al, rawA[0], As0, ltid);
@@ -281,6 +348,12 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
         __syncthreads();
         const unsigned long long t3 = __builtin_amdgcn_s_memtime();
         t_st += t1 - t0; t_is += t2 - t1; t_ba += t3 - t2;
+#elif defined(VQA_EXP_SKIP_LOAD)   // timing experiments only: the MFMA side alone
+        __syncthreads();
+#elif defined(VQA_EXP_SKIP_STORE)  // timing experiments only: global loads without the LDS stores
+        al.issue(ks + d + 1 + D, rawA[d]);
+        bl.issue(ks + d + 1 + D, rawB[d]);
+        __syncthreads();
 #else
         stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * Cfg::ABUF, ltid);
         al.issue(ks + d + 1 + D, rawA[d]);
@@ -307,7 +380,7 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const float* const As0 = smem;
   const float* const Bs0 = smem + 2 * Cfg::ABUF;
-  __builtin_amdgcn_s_setprio(3);   // MFMA waves win issue arbitration over the loader waves of their SIMD
+  __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);   // MFMA waves win issue arbitration over the loader waves of their SIMD
 #ifdef VQA_DIAG
   unsigned long long t_mma = 0, t_bar = 0;
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -320,8 +393,10 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
 #ifdef VQA_DIAG
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifndef VQA_EXP_SKIP_MFMA   // timing experiments only (tools/build_variant.sh): results are garbage
     if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, AR, BR, 1>(Ac, Bc, acc, wm, wn, lane);
     else mma_steps<Cfg, AR, BR, 4>(Ac, Bc, acc, wm, wn, lane);
+#endif
 #ifdef VQA_DIAG
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -407,7 +482,7 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const float* const As0 = smem;
   const float* const Bs0 = smem + 2 * Cfg::ABUF;
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
   __syncthreads();
   int s = 0;
   for (int tile = first; tile < ntiles; tile += stride) {

@@ -392,11 +392,11 @@ def test_persistent_tiles_forced(persistent, monkeypatch):
     test_gemm_epilogue_bias_rowgroup_relu_accumulate()
 
 
-@pytest.mark.parametrize("big", ["0", "1", "2"])
+@pytest.mark.parametrize("big", ["0", "1", "2", "3"])
 def test_tile_configurations_forced(big, monkeypatch):
     """The 256-row / 8-MFMA-wave tile configurations are normally chosen by problem size (only the bench
     shapes reach them); VQA_BIG_TILES forces each choice so that every compiled kernel is parity-checked:
-    0 = 128-row tiles everywhere, 1 = 256x128 / 256x64 conv forward + dgrad, 2 = 256x128 generic GEMM."""
+    0 = 128-row tiles everywhere, 1 = 256x128 / 256x64 conv forward + dgrad, 2 = 256x128 generic GEMM, 3 = 256-row conv forward + dgrad tiles with 8 loader waves (1024 threads)."""
     monkeypatch.setenv("VQA_BIG_TILES", big)
     test_conv_relu_pool_fwd_bwd(2, 58, 58, 64, 128, 1)
     test_conv_relu_pool_fwd_bwd(1, 30, 30, 128, 256, 1)

@@ -108,6 +108,14 @@ def main():
     w1 = torch.randn(1024, 2560, device=dev)
     h1 = torch.empty(B, 1024, device=dev)
     run("lin1_fwd", 2.0 * B * 2560 * 1024, lambda: ops.gemm(comb, w1, h1, B, 1024, 2560))
+    # square GEMMs: the engine's ceiling with the plain loaders (no conv addressing)
+    S = 4096
+    a = torch.randn(S, S, device=dev)
+    bm = torch.randn(S, S, device=dev)
+    cm = torch.empty(S, S, device=dev)
+    run("sq4096_nt", 2.0 * S ** 3, lambda: ops.gemm(a, bm, cm, S, S, S))
+    run("sq4096_nn", 2.0 * S ** 3, lambda: ops.gemm(a, bm, cm, S, S, S, transB=False, lda=S, ldb=S))
+    run("sq4096_tn", 2.0 * S ** 3, lambda: ops.gemm(a, bm, cm, S, S, S, transA=True, transB=False, lda=S, ldb=S))
     tot = sum(r[1] for r in res)
     print(f"sum of listed kernels: {tot:.3f} ms")
 

@@ -41,11 +41,11 @@ static int set_smem(K kern, int bytes, const char* what) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
 }
 
-template <class Cfg>
+template <class Cfg, bool U>
 static int launch_fwd(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* amax,
                       const ConvGeom& g, hipStream_t s) {
   const int nWin = g.B * g.Hp * g.Wp, K = 9 * g.CiP;
-  typename ConvFwdA<Cfg::NVA, Cfg::LT>::Params pa{x, g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
+  typename ConvFwdA<Cfg::NVA, Cfg::LT, U>::Params pa{x, g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
   typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wf, g.Co, g.Co, K};
   const int tiles_m = (4 * nWin + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.Co + Cfg::BN - 1) / Cfg::BN;
   const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2), tiles = tiles_m * tiles_n;
@@ -55,14 +55,14 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   // tile's prologue and epilogue), so they are opt-in (VQA_PERSISTENT=1) and parity-tested that way.
   const bool persistent = pt && pt[0] == '1';
   if (persistent) {
-    auto pk = conv_fwd_persistent_kernel<typename Cfg::Persistent>;
+    auto pk = conv_fwd_persistent_kernel<typename Cfg::Persistent, U>;
     static bool done2 = false;
     if (!done2) { int rc = set_smem(pk, Cfg::SMEM_BYTES, "attr(conv_fwd_p)"); if (rc) return rc; done2 = true; }
     hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, bias,
                        pooled, amax, g.Co, tiles_m, tiles_n, (K + BK - 1) / BK);
     return check_hip(hipGetLastError(), "conv_fwd_persistent launch");
   }
-  auto kern = conv_fwd_kernel<Cfg>;
+  auto kern = conv_fwd_kernel<Cfg, U>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_fwd)"); if (rc) return rc; done = true; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, bias, pooled, amax,
@@ -70,25 +70,25 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   return check_hip(hipGetLastError(), "conv_fwd launch");
 }
 
-template <class Cfg>
+template <class Cfg, bool U>
 static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, float* dx, const ConvGeom& g,
                         hipStream_t s) {
   const int rows = g.B * g.H * g.W, K = 9 * g.Co;
-  typename ConvDgradA<Cfg::NVA, Cfg::LT>::Params pa{dp, am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
+  typename ConvDgradA<Cfg::NVA, Cfg::LT, U>::Params pa{dp, am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
   typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wd, g.CiP, g.CiP, K};
   const int tiles_m = (rows + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.CiP + Cfg::BN - 1) / Cfg::BN;
   const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2), tiles = tiles_m * tiles_n;
   const char* pt = getenv("VQA_PERSISTENT");
   const bool persistent = pt && pt[0] == '1';   // see launch_fwd
   if (persistent) {
-    auto pk = conv_dgrad_persistent_kernel<typename Cfg::Persistent>;
+    auto pk = conv_dgrad_persistent_kernel<typename Cfg::Persistent, U>;
     static bool done2 = false;
     if (!done2) { int rc = set_smem(pk, Cfg::SMEM_BYTES, "attr(conv_dgrad_p)"); if (rc) return rc; done2 = true; }
     hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, dx,
                        g.CiP, tiles_m, tiles_n, (K + BK - 1) / BK);
     return check_hip(hipGetLastError(), "conv_dgrad_persistent launch");
   }
-  auto kern = conv_dgrad_kernel<Cfg>;
+  auto kern = conv_dgrad_kernel<Cfg, U>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_dgrad)"); if (rc) return rc; done = true; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, dx, g.CiP, tiles_m,
@@ -118,13 +118,13 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
   return p;
 }
 
-template <class Cfg>
+template <class Cfg, bool U>
 static int launch_wgrad(const float* x, const float* dp, const uint8_t* am, float* slab, float* bias_slab,
                         const ConvGeom& g, const WgradPlan& p, hipStream_t s) {
   WgradGeom wg{g.H, g.W, g.CiP, g.Hp, g.Wp, g.Co, g.stride, p.Mtot};
-  typename WgradA<Cfg::NVA, Cfg::LT>::Params pa{x, wg, p.KI};
-  typename WgradB<Cfg::NVB, Cfg::LT>::Params pb{dp, am, wg};
-  auto kern = conv_wgrad_kernel<Cfg>;
+  typename WgradA<Cfg::NVA, Cfg::LT, U>::Params pa{x, wg, p.KI};
+  typename WgradB<Cfg::NVB, Cfg::LT, U>::Params pb{dp, am, wg};
+  auto kern = conv_wgrad_kernel<Cfg, U>;
   static bool done = false;
   if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_wgrad)"); if (rc) return rc; done = true; }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, slab,
@@ -182,10 +182,12 @@ int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias
   const char* bt = getenv("VQA_BIG_TILES");
   const bool many_rows = bt && bt[0] == '1' ? true
                        : ((int64_t)4 * B * g.Hp * g.Wp >= 256 * 1024 && !(bt && bt[0] == '0'));
-  if (bt && bt[0] == '3' && Co > 64) return launch_fwd<Cfg256x128L8>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
-  if (Co > 64) return many_rows ? launch_fwd<Cfg256x128>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream)
-                                : launch_fwd<Cfg128>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
-  return launch_fwd<Cfg128x64>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
+  // channel counts that are not multiples of BK take the general per-lane-tap loaders (one tile shape)
+  if (CiP % BK != 0) return launch_fwd<Cfg128x64, false>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
+  if (bt && bt[0] == '3' && Co > 64) return launch_fwd<Cfg256x128L8, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
+  if (Co > 64) return many_rows ? launch_fwd<Cfg256x128, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream)
+                                : launch_fwd<Cfg128, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
+  return launch_fwd<Cfg128x64, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
 }
 
 int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* wd, float* dx, int B, int H, int W,
@@ -198,13 +200,14 @@ int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* 
   ProfScope prof(VQA_K_CONV_DGRAD, (hipStream_t)stream);
   const char* bt = getenv("VQA_BIG_TILES");
   const bool many_rows = bt && bt[0] == '1';   // opt-in only, see vqa_conv3x3_relu_pool_fwd
+  if (Co % BK != 0) return launch_dgrad<Cfg128x64, false>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
   if (bt && bt[0] == '3')
-    return CiP > 64 ? launch_dgrad<Cfg256x128L8>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
-                    : launch_dgrad<Cfg256x64L8>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
-  if (CiP > 64) return many_rows ? launch_dgrad<Cfg256x128>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
-                                 : launch_dgrad<Cfg128>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
-  return many_rows ? launch_dgrad<Cfg256x64>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
-                   : launch_dgrad<Cfg128x64>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
+    return CiP > 64 ? launch_dgrad<Cfg256x128L8, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
+                    : launch_dgrad<Cfg256x64L8, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
+  if (CiP > 64) return many_rows ? launch_dgrad<Cfg256x128, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
+                                 : launch_dgrad<Cfg128, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
+  return many_rows ? launch_dgrad<Cfg256x64, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
+                   : launch_dgrad<Cfg128x64, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
 }
 
 int64_t vqa_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride) {
@@ -236,8 +239,11 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
   {
     ProfScope prof(VQA_K_CONV_WGRAD, s);
     float* bias_slab = workspace + slab_bytes / 4;
-    rc = p.big ? launch_wgrad<Cfg128>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
-               : launch_wgrad<Cfg64>(x, dpooled, argmax, workspace, bias_slab, g, p, s);
+    const bool uni = CiP % BK == 0 && Co % BK == 0;
+    rc = p.big ? (uni ? launch_wgrad<Cfg128, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
+                      : launch_wgrad<Cfg128, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
+               : (uni ? launch_wgrad<Cfg64, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
+                      : launch_wgrad<Cfg64, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s));
     if (rc) return rc;
     const int total = Co * Ci * 9;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, workspace, dw, p.splits,

@@ -140,7 +140,7 @@ static int check_geom(const char* fn, const ConvGeom& g) {
   VQA_REQUIRE(g.Hp > 0 && g.Wp > 0, "%s: image too small for conv+pool", fn);
   VQA_REQUIRE((int64_t)g.B * g.H * g.W < (1LL << 31) / 4, "%s: too many pixels for 32-bit row indices", fn);
   // the loaders address each tensor with 32-bit byte offsets from its first element
-  VQA_REQUIRE((int64_t)g.B * g.H * g.W * g.CiP * 4 < (1LL << 32) - 4096 && (int64_t)g.B * g.Hp * g.Wp * g.Co * 4 < (1LL << 32) - 4096,
+  VQA_REQUIRE((int64_t)g.B * g.H * g.W * g.CiP * 4 < 0xffff0000LL && (int64_t)g.B * g.Hp * g.Wp * g.Co * 4 < 0xffff0000LL,
               "%s: a tensor of this layer reaches 4 GiB (B=%d): split the batch", fn, g.B);
   return VQA_OK;
 }
@@ -239,7 +239,7 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
   {
     ProfScope prof(VQA_K_CONV_WGRAD, s);
     float* bias_slab = workspace + slab_bytes / 4;
-    const bool uni = CiP % BK == 0 && Co % BK == 0;
+    const bool uni = CiP % BK == 0 && Co % BK == 0 && 2 * g.Wp >= BK;
     rc = p.big ? (uni ? launch_wgrad<Cfg128, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
                       : launch_wgrad<Cfg128, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
                : (uni ? launch_wgrad<Cfg64, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)

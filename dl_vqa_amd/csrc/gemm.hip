@@ -151,11 +151,15 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_kernel(type
   const int split = tc.split;
   const int ks0 = split * ks_per_split;
   const int ks1 = min(nk, ks0 + ks_per_split);
-  AL al; al.init(pa, m0, loader_tid<Cfg>(), ks0);
-  BL bl; bl.init(pb, n0, loader_tid<Cfg>(), ks0);
   f32x16 acc[Cfg::TM][Cfg::TN];
   acc_zero<Cfg>(acc);
-  if (!gemm_mainloop<Cfg>(al, bl, acc, ks0, ks1, Ktot, smem)) return;
+  if (!gemm_mainloop<Cfg, AL, BL>(
+          [&](AL& al, BL& bl) {
+            al.init(pa, m0, loader_tid<Cfg>(), ks0);
+            bl.init(pb, n0, loader_tid<Cfg>(), ks0);
+          },
+          [](AL&, BL&) {}, acc, ks0, ks1, Ktot, smem))
+    return;
 
   float* slab = pe.slab ? pe.slab + (int64_t)split * pe.M * pe.N : nullptr;
   if (slab) {

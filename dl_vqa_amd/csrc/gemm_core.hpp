@@ -132,8 +132,9 @@ __device__ __forceinline__ float4 mask4(float4 v, bool on, int e0, int len) {
 // past the end are lanes whose offset is BUF_OOB: the hardware range check returns zeros for them, which
 // replaces both the address clamp and the v_cndmask masking of a plain global load.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t BUF_OOB = 0xfffffff0u;   // >= any num_records: the lane reads zeros, no memory access
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, uint32_t bytes = 0xffffff00u) {
+// BUF_OOB (+ any immediate offset, no 32-bit wrap) >= num_records: the lane reads zeros, no memory access
+constexpr uint32_t BUF_OOB = 0xffff0000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, uint32_t bytes = 0xffff0000u) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff = 0) {
@@ -416,12 +417,18 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
 
 // Whole contraction over K-steps [ks0, ks1) (ks1 > ks0).  Returns true for MFMA waves (which hold the
 // accumulators and run the epilogue); loader waves return false and must do nothing further that
-// needs a barrier.
-template <class Cfg, class AL, class BL, bool SHORT_TAIL = false>
-__device__ __forceinline__ bool gemm_mainloop(AL& al, BL& bl, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
-                                              int Ktot, float* smem) {
+// needs a barrier.  The loaders live entirely inside the loader branch -- init(al, bl) sets them up,
+// done(al, bl) runs after the last K-step -- so that MFMA waves spend no VALU on them and, as important,
+// so that their wave-uniform state stays in SGPRs (a value defined under the role test and used after
+// the join would count as divergent).
+template <class Cfg, class AL, class BL, bool SHORT_TAIL = false, class Init, class Done>
+__device__ __forceinline__ bool gemm_mainloop(Init&& init, Done&& done, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0,
+                                              int ks1, int Ktot, float* smem) {
   if (is_loader_wave<Cfg>()) {
+    AL al; BL bl;
+    init(al, bl);
     loader_loop<Cfg>(al, bl, ks0, ks1, smem);
+    done(al, bl);
     return false;
   }
   mfma_loop<Cfg, AL::kTypeR, BL::kTypeR, SHORT_TAIL>(acc, ks0, ks1, Ktot, smem);

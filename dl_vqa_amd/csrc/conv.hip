@@ -31,6 +31,8 @@ using Cfg128x64 = TileCfg<128, 64, 2, 2>;
 using Cfg256x128 = TileCfg<256, 128, 4, 2>;   // 8 MFMA waves (64x64 each) + 4 loader waves, one workgroup per CU
 using Cfg256x64 = TileCfg<256, 64, 4, 2>;     // 8 MFMA waves (64x32 each)
 using Cfg64 = TileCfg<64, 64, 2, 2>;
+// wgrad rows are (tap, ci): 9*CiP = 576 for CiP = 64 is 4.5 x 128 but 6 x 96 (1 x 4 MFMA waves of 96x32)
+using Cfg96x128 = TileCfg<96, 128, 1, 4>;
 // the same tiles with 8 loader waves (1024 threads): two loader waves per SIMD for loader-bound K loops
 using Cfg256x128L8 = TileCfg<256, 128, 4, 2, 8>;
 using Cfg256x64L8 = TileCfg<256, 64, 4, 2, 8>;
@@ -96,15 +98,17 @@ static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, flo
   return check_hip(hipGetLastError(), "conv_dgrad launch");
 }
 
-struct WgradPlan { int big, tiles_m, tiles_n, nk, splits, ks_per_split, Mtot, KI; };
+struct WgradPlan { int big, bm, tiles_m, tiles_n, nk, splits, ks_per_split, Mtot, KI; };
 static WgradPlan plan_wgrad(const ConvGeom& g) {
   WgradPlan p;
   p.KI = 9 * g.CiP;
   p.Mtot = g.B * 2 * g.Hp * 2 * g.Wp;
   p.big = (p.KI >= 128 && g.Co >= 128) ? 1 : 0;
-  const int bm = p.big ? 128 : 64;
-  p.tiles_m = (p.KI + bm - 1) / bm;
-  p.tiles_n = (g.Co + bm - 1) / bm;
+  const int bn = p.big ? 128 : 64;
+  // 96-row tiles when they waste fewer rows than 128-row tiles (KI = 576: 576 vs 640 rows of MFMA work)
+  p.bm = !p.big ? 64 : ((p.KI + 95) / 96 * 96 < (p.KI + 127) / 128 * 128 ? 96 : 128);
+  p.tiles_m = (p.KI + p.bm - 1) / p.bm;
+  p.tiles_n = (g.Co + bn - 1) / bn;
   p.nk = (p.Mtot + BK - 1) / BK;
   const int tiles = p.tiles_m * p.tiles_n;
   // 2 workgroups fit a CU (LDS): tiles * splits must not exceed the 512 resident slots, or the few
@@ -176,12 +180,12 @@ int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias
   if (rc) return rc;
   set_launch_tag(tag);
   ProfScope prof(VQA_K_CONV_FWD, (hipStream_t)stream);
-  // 256x128 tiles (8 MFMA waves + 4 loader waves, one workgroup per CU) measured +2 % on forward (74-75 %
-  // vs 72-73 %), whose loader is cheap; on dgrad the routing loader becomes the critical path with only one
-  // loader wave per SIMD (51-62 % vs 64-70 %), so dgrad keeps 128-row tiles.  VQA_BIG_TILES=0/1 overrides.
+  // Two 128x128 workgroups per CU beat one 256x128 workgroup (8 MFMA + 4 or 8 loader waves) since the loaders
+  // left the VALU: conv1 / conv2 forward 84.4 / 88.3 % against 82.7 / 84.7 % (4 loader waves) and 83.6 / 85.2 %
+  // (8); on dgrad the gap is wider (72 / 81 % against 56 / 70 % and 66 / 75 %).  The 256-row kernels stay
+  // selectable with VQA_BIG_TILES=1 (4 loader waves) / 3 (8) and are parity-tested that way.
   const char* bt = getenv("VQA_BIG_TILES");
-  const bool many_rows = bt && bt[0] == '1' ? true
-                       : ((int64_t)4 * B * g.Hp * g.Wp >= 256 * 1024 && !(bt && bt[0] == '0'));
+  const bool many_rows = bt && bt[0] == '1';
   // channel counts that are not multiples of BK take the general per-lane-tap loaders (one tile shape)
   if (CiP % BK != 0) return launch_fwd<Cfg128x64, false>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
   if (bt && bt[0] == '3' && Co > 64) return launch_fwd<Cfg256x128L8, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
@@ -240,17 +244,18 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
     ProfScope prof(VQA_K_CONV_WGRAD, s);
     float* bias_slab = workspace + slab_bytes / 4;
     const bool uni = CiP % BK == 0 && Co % BK == 0 && 2 * g.Wp >= BK;
-    rc = p.big ? (uni ? launch_wgrad<Cfg128, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
+    rc = p.bm == 96 ? (uni ? launch_wgrad<Cfg96x128, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
+                           : launch_wgrad<Cfg96x128, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
+       : p.big ? (uni ? launch_wgrad<Cfg128, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
                       : launch_wgrad<Cfg128, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
                : (uni ? launch_wgrad<Cfg64, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
                       : launch_wgrad<Cfg64, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s));
     if (rc) return rc;
-    const int total = Co * Ci * 9;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, workspace, dw, p.splits,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((p.KI * Co + 63) / 64), dim3(256), 0, s, workspace, dw, p.splits,
                        p.KI, CiP, Ci, Co);
     rc = check_hip(hipGetLastError(), "wgrad_reduce launch");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 255) / 256), dim3(256), 0, s, bias_slab, dbias,
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bias_slab, dbias,
                        p.splits * 4, Co);
     rc = check_hip(hipGetLastError(), "wgrad_bias_reduce launch");
   }

@@ -4,6 +4,7 @@
 #include <mutex>
 #include <vector>
 
+#include <type_traits>
 #include "gemm_core.hpp"
 
 namespace vqa {
@@ -67,48 +68,102 @@ __device__ __forceinline__ float epi_apply(const EpiParams& e, float v, int row,
   return v;
 }
 
+// Fused epilogue.  gfx950 counts stores and loads in the same vmcnt, so a load anywhere inside the per-element
+// code makes every element wait for the previous element's STORE to be acknowledged (measured: 64 elements x
+// ~1000 cycles per tile, more than the K loop of a K = 256 GEMM).  The per-element code is therefore
+// load-free: the mode is decided once per tile, per-column terms and the (at most two) row-group terms of a
+// tile are loaded up front, and the `accumulate` / general row-group loads of a 32x32 accumulator tile are
+// issued as one batch of 16 before its 16 stores.
+//   RG: 0 none, 1 row-group term with rg_div >= BM (the tile spans at most two groups: q' tiled over the
+//       676 image positions of a sample), 2 general (one division per element)
+// Addressing: a 32x32 accumulator tile is stored through a buffer resource whose base is the tile's first
+// element (scalar); the lane's part -- row 4*(lane>>5), column lane&31 -- is one VGPR for the whole epilogue
+// and element r's row offset is a scalar, so a store costs no VALU instruction.  Interior tiles (the common
+// case) carry no per-element predicate either; on edge tiles an invalid element's offset becomes BUF_OOB
+// and the hardware drops the store.
+template <class Cfg, int RG, bool ACC, bool AUX>
+__device__ __forceinline__ void gemm_epilogue_mode(const EpiParams& pe, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0,
+                                                   int n0, int wm, int wn, int lane) {
+  const int g0 = RG ? m0 / pe.rg_div : 0;
+  const int boundary = (g0 + 1) * pe.rg_div;
+  const bool mul = pe.rg_op != 0, relu = pe.relu != 0;
+  // ACC / AUX say what the instantiation supports; the general instantiations still honour the run-time flags
+  const bool accum = ACC && pe.accumulate != 0, aux = AUX && pe.aux != nullptr;
+  const bool interior = m0 + Cfg::BM <= pe.M && n0 + Cfg::BN <= pe.N;       // uniform
+  const bool one_group = RG == 1 && boundary >= m0 + Cfg::BM;               // uniform: rg1 never selected
+  const uint32_t ldb = (uint32_t)pe.ldc * 4u;                               // ldc < 2^21 (checked on entry)
+  const uint32_t vlane = (uint32_t)(4 * (lane >> 5)) * ldb + 4u * (uint32_t)(lane & 31);
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int colt = n0 + wn * Cfg::WN + 32 * j;          // tile's first column (uniform)
+    const int col = colt + (lane & 31);
+    const bool cok = col < pe.N;
+    const int cc = cok ? col : 0;
+    float cb = 0.f;
+    if (pe.bias1) cb += pe.bias1[cc];
+    if (pe.bias2) cb += pe.bias2[cc];
+    float rg0 = 0.f, rg1 = 0.f;
+    if (RG == 1) {
+      rg0 = pe.rg[(int64_t)g0 * pe.rg_ld + cc];
+      rg1 = (!one_group && boundary < pe.M) ? pe.rg[(int64_t)(g0 + 1) * pe.rg_ld + cc] : rg0;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      const int rowt = m0 + wm * Cfg::WM + 32 * i;        // tile's first row (uniform)
+      const int row0 = rowt + 4 * (lane >> 5);
+      const __amdgpu_buffer_rsrc_t rc = buf_rsrc(pe.C + (int64_t)rowt * pe.ldc + colt);
+      const __amdgpu_buffer_rsrc_t rx = buf_rsrc((aux ? pe.aux : pe.C) + (int64_t)rowt * pe.ldc + colt);
+      auto tile = [&](auto inner) {
+        constexpr bool INNER = decltype(inner)::value;
+        auto vo = [&](int dr) { return INNER || (cok && row0 + dr < pe.M) ? vlane : BUF_OOB; };
+        float old[16], g[16];
+        if (accum) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            old[r] = __uint_as_float(buf_load4(rc, vo(dr), (uint32_t)dr * ldb));
+          }
+        }
+        if (RG == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            g[r] = pe.rg[(int64_t)((row < pe.M ? row : 0) / pe.rg_div) * pe.rg_ld + cc];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r];
+          if (aux) buf_store4(rx, v, vo(dr), (uint32_t)dr * ldb);
+          if (RG) {
+            const float t = RG == 2 ? g[r] : (one_group || row0 + dr < boundary) ? rg0 : rg1;
+            v = mul ? v * t : v + t;
+          }
+          v += cb;
+          if (relu) v = fmaxf(v, 0.f);
+          if (accum) v += old[r];
+          buf_store4(rc, v, vo(dr), (uint32_t)dr * ldb);
+        }
+      };
+      if (interior) tile(std::true_type{}); else tile(std::false_type{});
+    }
+  }
+}
+
 template <class Cfg>
 __device__ __forceinline__ void gemm_epilogue(const EpiParams& pe, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
                                               int wm, int wn, int lane) {
-  // Fused epilogue.  Per-column terms are loaded once per column; the row-group term (q' tiled over the
-  // image positions of a sample) needs row / rg_div: when a group is at least as tall as the tile
-  // (P = 676 >= 128) the tile spans at most two groups, so one division per workgroup replaces one per element.
-  const bool two_groups = pe.rg && pe.rg_div >= Cfg::BM;
-  const int g0 = pe.rg ? m0 / pe.rg_div : 0;
-  const int boundary = (g0 + 1) * pe.rg_div;
-#pragma unroll
-  for (int j = 0; j < Cfg::TN; ++j) {
-    const int col = n0 + acc_col<Cfg>(wn, j, lane);
-    const bool cok = col < pe.N;
-    float cb = 0.f;
-    if (cok && pe.bias1) cb += pe.bias1[col];
-    if (cok && pe.bias2) cb += pe.bias2[col];
-    float rg0 = 0.f, rg1 = 0.f;
-    if (two_groups && cok) {
-      rg0 = pe.rg[(int64_t)g0 * pe.rg_ld + col];
-      rg1 = boundary < pe.M ? pe.rg[(int64_t)(g0 + 1) * pe.rg_ld + col] : rg0;
-    }
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
-        if (row < pe.M && cok) {
-          float v = acc[i][j][r];
-          const int64_t o = (int64_t)row * pe.ldc + col;
-          if (pe.aux) pe.aux[o] = v;
-          if (pe.rg) {
-            const float g = two_groups ? (row >= boundary ? rg1 : rg0)
-                                       : pe.rg[(int64_t)(row / pe.rg_div) * pe.rg_ld + col];
-            v = pe.rg_op ? v * g : v + g;
-          }
-          v += cb;
-          if (pe.relu) v = fmaxf(v, 0.f);
-          if (pe.accumulate) v += pe.C[o];
-          pe.C[o] = v;
-        }
-      }
-  }
+  const int rg = !pe.rg ? 0 : (pe.rg_div >= Cfg::BM ? 1 : 2);
+  const bool a = pe.accumulate != 0, x = pe.aux != nullptr;
+  // the combinations the train step uses get their own straight-line code; the rest share the general one
+  if (rg == 0 && !a && !x) return gemm_epilogue_mode<Cfg, 0, false, false>(pe, acc, m0, n0, wm, wn, lane);
+  if (rg == 0 && a && !x) return gemm_epilogue_mode<Cfg, 0, true, false>(pe, acc, m0, n0, wm, wn, lane);
+  if (rg == 1 && !a && !x) return gemm_epilogue_mode<Cfg, 1, false, false>(pe, acc, m0, n0, wm, wn, lane);
+  if (rg == 0 && !a && x) return gemm_epilogue_mode<Cfg, 0, false, true>(pe, acc, m0, n0, wm, wn, lane);
+  if (rg == 1) return gemm_epilogue_mode<Cfg, 1, true, true>(pe, acc, m0, n0, wm, wn, lane);
+  if (rg == 2) return gemm_epilogue_mode<Cfg, 2, true, true>(pe, acc, m0, n0, wm, wn, lane);
+  return gemm_epilogue_mode<Cfg, 0, true, true>(pe, acc, m0, n0, wm, wn, lane);
 }
 
 // Persistent variant (no split-K, single Raw set): min(tiles, resident slots) workgroups walk the tiles.
@@ -163,17 +218,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_kernel(type
 
   float* slab = pe.slab ? pe.slab + (int64_t)split * pe.M * pe.N : nullptr;
   if (slab) {
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {
-        const int col = n0 + acc_col<Cfg>(wn, j, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + acc_row<Cfg>(wm, i, r, lane);
-          if (row < pe.M && col < pe.N) slab[(int64_t)row * pe.N + col] = acc[i][j][r];
-        }
-      }
+    store_acc_tiles<Cfg>(acc, slab, pe.N, pe.M, pe.N, m0, n0, wm, wn, lane);
     return;
   }
   gemm_epilogue<Cfg>(pe, acc, m0, n0, wm, wn, lane);
@@ -343,8 +388,9 @@ int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ld
   VQA_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && lda % 4 == 0 && ldb % 4 == 0,
               "vqa_gemm: A/B must be 16-byte aligned with leading dimensions multiple of 4 (lda=%lld ldb=%lld)",
               (long long)lda, (long long)ldb);
-  VQA_REQUIRE(lda < (1 << 21) && ldb < (1 << 21), "vqa_gemm: leading dimensions must be below 2^21 (lda=%lld ldb=%lld)",
-              (long long)lda, (long long)ldb);
+  VQA_REQUIRE(lda < (1 << 21) && ldb < (1 << 21) && ldc < (1 << 21),
+              "vqa_gemm: leading dimensions must be below 2^21 (lda=%lld ldb=%lld ldc=%lld)", (long long)lda,
+              (long long)ldb, (long long)ldc);
   VQA_REQUIRE(!rowgroup || rg_div > 0, "vqa_gemm: rg_div must be positive");
   hipStream_t s = (hipStream_t)stream;
   const GemmPlan p = plan_gemm(M, N, K);

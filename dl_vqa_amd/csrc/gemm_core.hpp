@@ -20,6 +20,7 @@
 //     applies masks / arg-max routing when the data is written to LDS one or more K-steps later
 //     (a predicated load makes hipcc branch and wait per load).
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace vqa {
@@ -38,6 +39,9 @@ static __device__ unsigned long long vqa_diag_ld[4];
 // wave priorities of the two roles (s_setprio), overridable for experiments
 #ifndef VQA_PRIO_MFMA
 #define VQA_PRIO_MFMA 3
+#endif
+#ifndef VQA_PF128
+#define VQA_PF128 2   // K-steps of loads in flight for tiles up to 128x128
 #endif
 #ifndef VQA_PRIO_LOADER
 #define VQA_PRIO_LOADER 0
@@ -71,7 +75,7 @@ struct TileCfg {
   // K-steps of global loads a loader thread keeps in flight (register ring).  A 64x64 tile's K-step is
   // only 1024 MFMA cycles (~0.45 us), shorter than an L2 round trip, so it needs 3 steps of run-ahead;
   // the big tiles' K-steps (>= 4096 cycles) cover the latency with one and have no registers to spare.
-  static constexpr int PREFETCH = PREFETCH_ ? PREFETCH_ : (BM * BN <= 64 * 64) ? 3 : (BM * BN <= 128 * 128) ? 2 : 1;
+  static constexpr int PREFETCH = PREFETCH_ ? PREFETCH_ : (BM * BN <= 64 * 64) ? 3 : (BM * BN <= 128 * 128) ? VQA_PF128 : 1;
   // the persistent-tile loop re-initialises its loaders at tile seams and needs a single Raw set
   using Persistent = TileCfg<BM_, BN_, WAVES_M_, WAVES_N_, LOADER_WAVES_, 1>;
 };
@@ -143,6 +147,13 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t 
 }
 __device__ __forceinline__ uint32_t buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff = 0) {
   return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, float v, uint32_t voff, uint32_t soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, uint8_t v, uint32_t voff, uint32_t soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b8(v, r, (int)voff, (int)soff, 0);
 }
 
 // ---------------------------------------------------------------- plain matrix loaders
@@ -531,6 +542,36 @@ __device__ __forceinline__ int acc_row(int wm, int i, int r, int lane) {
 template <class Cfg>
 __device__ __forceinline__ int acc_col(int wn, int j, int lane) {
   return wn * Cfg::WN + 32 * j + (lane & 31);
+}
+
+// Plain store of the accumulators to a row-major matrix out[rows][ld] (dgrad's dx, the split-K slabs).
+// Buffer resource based at each 32x32 tile's first element: the lane's part (row 4*(lane>>5), column
+// lane&31) is one VGPR for the whole epilogue, element r's row a scalar offset; interior tiles carry no
+// predicate, on edge tiles an invalid element's offset is BUF_OOB and the hardware drops the store.
+template <class Cfg>
+__device__ __forceinline__ void store_acc_tiles(f32x16 (&acc)[Cfg::TM][Cfg::TN], float* out, int64_t ld, int rows,
+                                                int cols, int m0, int n0, int wm, int wn, int lane) {
+  const bool interior = m0 + Cfg::BM <= rows && n0 + Cfg::BN <= cols;       // uniform
+  const uint32_t ldb = (uint32_t)ld * 4u;
+  const uint32_t vl = (uint32_t)(4 * (lane >> 5)) * ldb + 4u * (uint32_t)(lane & 31);
+  auto body = [&](auto inner) {
+    constexpr bool INNER = decltype(inner)::value;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int rowt = m0 + wm * Cfg::WM + 32 * i, colt = n0 + wn * Cfg::WN + 32 * j;
+        const __amdgpu_buffer_rsrc_t rs = buf_rsrc(out + (int64_t)rowt * ld + colt);
+        const bool cok = colt + (lane & 31) < cols;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          const bool ok = INNER || (cok && rowt + 4 * (lane >> 5) + dr < rows);
+          buf_store4(rs, acc[i][j][r], ok ? vl : BUF_OOB, (uint32_t)dr * ldb);
+        }
+      }
+  };
+  if (interior) body(std::true_type{}); else body(std::false_type{});
 }
 
 // Workgroup id -> (mt, nt, split).  The grid is one-dimensional; logical ids run nt fastest, then

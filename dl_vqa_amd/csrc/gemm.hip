@@ -245,19 +245,27 @@ static GemmPlan plan_gemm(int M, int N, int K) {
   const int t128 = ((M + 127) / 128) * ((N + 127) / 128);
   const int t64 = ((M + 63) / 64) * ((N + 63) / 64);
   int splits = 1;
-  if (t128 >= 200) p.big = 1;
-  else if (t64 >= 200) p.big = 0;
+  // Two workgroups fit a CU: 512 resident slots.  A launch that fills them exactly keeps two MFMA waves on
+  // every SIMD (one covers the other's barriers); 384 workgroups left a quarter of the slots empty
+  // (v_conv dW 0.90 -> 0.72 ms with 24 -> 32 splits), more than 512 would run a second, nearly empty round.
+  const char* st = getenv("VQA_SPLIT_TARGET");
+  const int target = st ? atoi(st) : 512;
+  if (t128 >= 200) {
+    p.big = 1;
+    // 200..511 big tiles with a long K: two splits double the resident workgroups (LSTM dW_hh: 256 tiles)
+    if (t128 * 2 <= target && nk >= 64) splits = target / t128;
+  } else if (t64 >= 200) p.big = 0;
   else {
     // few big tiles + many splits = short K loops dominated by prologue/epilogue (LSTM dh GEMM, M = 256:
     // 16 tiles x 24 splits of 6 K-steps ran at 21 % of peak): below 64 big tiles use 64x64 tiles, whose
     // 4x larger tile count needs 4x fewer splits
     // ... unless K is long enough that every split of the big tiling still runs >= 16 K-steps
-    // (v_conv dW: K = B*P = 173k -> 16 tiles x 24 splits x 225 K-steps: 128x128 is 13 % faster there)
-    const int big_splits = (384 + t128 - 1) / t128;
+    // (v_conv dW: K = B*P = 173k -> 16 tiles x 32 splits x 169 K-steps)
+    const int big_splits = target / t128 > 1 ? target / t128 : 1;
     p.big = (M >= 128 && N >= 128 && (t128 >= 64 || nk / big_splits >= 16)) ? 1 : 0;
     const int tiles = p.big ? t128 : t64;
     const int max_splits = nk / 4 > 1 ? nk / 4 : 1;
-    splits = (384 + tiles - 1) / tiles;
+    splits = target / tiles > 1 ? target / tiles : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits > 64) splits = 64;
   }

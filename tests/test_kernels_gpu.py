@@ -34,7 +34,8 @@ def check(name, got, ref, tol):
 
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(300, 200, 100), (64, 64, 32), (5, 3, 8), (256, 1024, 2560),
-                                   (1030, 260, 3584), (129, 4096, 300)])
+                                   (1030, 260, 3584), (129, 4096, 300),
+                                   (70, 50, 45), (40, 33, 7), (200, 130, 1001)])   # K tails: K % 4 != 0, K < BK
 @pytest.mark.parametrize("transA,transB", [(False, True), (False, False), (True, True), (True, False)])
 def test_gemm_layouts(M, N, K, transA, transB):
     ops = _ops()
@@ -89,6 +90,37 @@ def test_gemm_epilogue_bias_rowgroup_relu_accumulate():
     check("gemm split-K epilogue", Cd, ref, 2e-5)
 
 
+@pytest.mark.parametrize("M_groups,P,N", [(3, 150, 36), (2, 676, 200), (5, 130, 64)])
+def test_gemm_epilogue_tall_rowgroups_and_aux(M_groups, P, N):
+    """Row-group terms whose groups are at least a tile tall (the attention shape: q' tiled over the P image
+    positions of a sample): tiles inside one group, tiles straddling a boundary, the last partial tile; with the
+    raw product also written to `aux`, with and without accumulate, add and multiply."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M_groups * 31 + P)
+    K = 72
+    M = M_groups * P
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    b1 = torch.randn(N, generator=g)
+    rg = torch.randn(M_groups, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    acc = A.double() @ W.double().t()
+    rgx = rg.double().repeat_interleave(P, dim=0)
+    for op, accumulate, relu in ((0, False, True), (1, False, False), (0, True, False), (1, True, True)):
+        ref = acc + rgx if op == 0 else acc * rgx
+        ref = ref + b1.double()
+        if relu:
+            ref = torch.relu(ref)
+        if accumulate:
+            ref = ref + C0.double()
+        Cd = C0.clone().to(DEV)
+        aux = torch.full((M, N), 3.0, device=DEV)
+        ops.gemm(A.to(DEV), W.to(DEV), Cd, M, N, K, bias1=b1.to(DEV), rowgroup=rg.to(DEV), rg_div=P, rg_op=op,
+                 relu=relu, accumulate=accumulate, aux=aux)
+        torch.cuda.synchronize()
+        check(f"gemm rowgroup P={P} op={op} acc={accumulate}", Cd, ref, 1e-5)
+        check(f"gemm aux P={P} op={op}", aux, acc, 1e-5)
+
+
 def test_gemm_rejects_misaligned():
     from dl_vqa_amd._lib import VqaHipError
     ops = _ops()
@@ -114,6 +146,11 @@ CONV_CASES = [  # B, H, W, Ci, Co, stride
     (2, 58, 58, 64, 128, 1),   # the conv1 shape family (128x128 tile)
     (1, 30, 30, 128, 256, 1),  # conv2 shape family
     (2, 40, 40, 4, 64, 1),     # conv0 shape family (NHWC4, 128x64 tile)
+    (2, 38, 42, 32, 96, 1),    # uniform-tap loaders, Co = 96: partial N tile, wgrad column groups past Co
+    (2, 20, 20, 32, 32, 1),    # 2*Wp = 18 < BK: uniform forward / dgrad, general (per-lane cursor) wgrad
+    (1, 36, 36, 48, 80, 1),    # channel counts that are no multiples of 32: general loaders everywhere
+    (2, 37, 41, 32, 64, 2),    # stride 2 through the uniform-tap loaders
+    (3, 34, 70, 64, 64, 1),    # wide rows: the wgrad row cursor wraps rows and images (Mtot % 32 != 0)
 ]
 
 

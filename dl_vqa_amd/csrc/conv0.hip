@@ -27,7 +27,14 @@ __host__ __device__ inline int c0_round_stride(int W, int want_mod) {
 }
 
 // ------------------------------------------------------------------ forward
-// grid (ceil(Hp/2), B); 256 threads; dynamic LDS = CI * 6 * RS floats (RS % 32 == 16)
+// grid (ceil(Hp/C0_FR), B); 256 threads; dynamic LDS = CI * C0_PR * RS floats (RS % 32 == 16).
+// A workgroup covers C0_FR pool rows (2*C0_FR + 2 image rows): with 4 rows the patch staging, the barrier and
+// the 28 weight-fragment loads are spread over 14 M-tiles per wave instead of 7.  The tile loop has no
+// integer division (window row by compares, 24-bit multiplies) and stores through a buffer resource based at
+// the workgroup's first window (lane part one VGPR per tile, group / column block in the scalar offset).
+constexpr int C0_FR = 4;
+constexpr int C0_PR = 2 * C0_FR + 2;
+
 template <int CI, int TN>
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* pooled, uint8_t* amax,
@@ -35,19 +42,19 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) float patch[];
   constexpr int K = 9 * CI, NS = (K + 1) / 2, Co = 32 * TN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y, py0 = 2 * blockIdx.x;
-  const int nwr = min(2, Hp - py0);
+  const int b = blockIdx.y, py0 = C0_FR * blockIdx.x;
+  const int nwr = min(C0_FR, Hp - py0);
   const int y0 = 2 * py0, nrows = 2 * nwr + 2;
-  const int plane = 6 * RS;
-  // stage the planar patch: rows y0 .. y0+nrows-1 of every input channel
-  for (int e = tid; e < CI * 6 * (W / 4); e += 256) {
-    const int c4 = e % (W / 4);
-    const int r = (e / (W / 4)) % 6;
-    const int c = e / (W / 4) / 6;
-    float4 v = f4zero();
-    if (r < nrows) v = *reinterpret_cast<const float4*>(x + ((int64_t)(b * CI + c) * H + y0 + r) * W + 4 * c4);
-    float* d = patch + c * plane + r * RS + 4 * c4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  const int plane = C0_PR * RS;
+  // stage the planar patch: rows y0 .. y0+nrows-1 of every input channel; a wave takes whole rows
+  for (int r = wave; r < CI * C0_PR; r += 4) {
+    const int c = r / C0_PR, rr = r - c * C0_PR;        // wave-uniform
+    const float* src = x + ((int64_t)(b * CI + c) * H + y0 + rr) * W;
+    float* dst = patch + c * plane + rr * RS;
+    for (int c4 = lane; c4 < W / 4; c4 += 64) {
+      const float4 v = rr < nrows ? *reinterpret_cast<const float4*>(src + 4 * c4) : f4zero();
+      dst[4 * c4] = v.x; dst[4 * c4 + 1] = v.y; dst[4 * c4 + 2] = v.z; dst[4 * c4 + 3] = v.w;
+    }
   }
   // weights as B fragments, tap offsets as per-lane constants
   float bf[NS][TN];
@@ -68,12 +75,16 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
   __syncthreads();
 
   const int nwin = nwr * Wp, ntiles = (nwin + 7) / 8;
+  // windows of the workgroup are consecutive in memory: offset = first window + wo * Co
+  const int64_t o0 = (int64_t)(b * Hp + py0) * Wp * Co;
+  const __amdgpu_buffer_rsrc_t rp = buf_rsrc(pooled + o0), ra = buf_rsrc(amax + o0);
   for (int t = wave; t < ntiles; t += 4) {
     // A rows: row i = 4*window + pixel (the engine's window-in-4-registers layout)
     int wdx = 8 * t + (l31 >> 2);
     if (wdx >= nwin) wdx = 0;
-    const int wr = wdx / Wp, px = wdx - wr * Wp, j4 = l31 & 3;
-    const float* ap = patch + (2 * wr + (j4 >> 1)) * RS + 2 * px + (j4 & 1);
+    const int wr = (wdx >= Wp ? 1 : 0) + (wdx >= 2 * Wp ? 1 : 0) + (wdx >= 3 * Wp ? 1 : 0);
+    const int px = wdx - __mul24(wr, Wp), j4 = l31 & 3;
+    const float* ap = patch + __mul24(2 * wr + (j4 >> 1), RS) + 2 * px + (j4 & 1);
     f32x16 acc[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -85,23 +96,22 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s][j], acc[j], 0, 0, 0);
     }
+    const bool inner = 8 * t + 8 <= nwin;                       // uniform
+    const uint32_t vl = (uint32_t)__mul24(8 * t + h, Co) + (uint32_t)l31;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int wo = 8 * t + 2 * g + h;
-      if (wo < nwin) {
-        const int wr2 = wo / Wp, px2 = wo - wr2 * Wp;
-        const int64_t o = ((int64_t)(b * Hp + py0 + wr2) * Wp + px2) * Co + l31;
+      const bool ok = inner || 8 * t + 2 * g + h < nwin;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float best = acc[j][4 * g];
-          int a = 0;
-          if (acc[j][4 * g + 1] > best) { best = acc[j][4 * g + 1]; a = 1; }
-          if (acc[j][4 * g + 2] > best) { best = acc[j][4 * g + 2]; a = 2; }
-          if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
-          best += bv[j];
-          pooled[o + 32 * j] = best > 0.f ? best : 0.f;
-          amax[o + 32 * j] = best > 0.f ? (uint8_t)a : (uint8_t)4;
-        }
+      for (int j = 0; j < TN; ++j) {
+        float best = acc[j][4 * g];
+        int a = 0;
+        if (acc[j][4 * g + 1] > best) { best = acc[j][4 * g + 1]; a = 1; }
+        if (acc[j][4 * g + 2] > best) { best = acc[j][4 * g + 2]; a = 2; }
+        if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
+        best += bv[j];
+        const uint32_t so = (uint32_t)(2 * g * Co + 32 * j);
+        buf_store4(rp, best > 0.f ? best : 0.f, ok ? 4u * vl : BUF_OOB, 4u * so);
+        buf_store1(ra, best > 0.f ? (uint8_t)a : (uint8_t)4, ok ? vl : BUF_OOB, so);
       }
     }
   }
@@ -214,7 +224,7 @@ static bool c0_supported(int Ci, int H, int W, int Co, int stride) {
   // wgrad maps the 9*Ci taps onto the 32 rows of one MFMA A operand: Ci <= 3
   if (!(Ci >= 1 && Ci <= 3 && stride == 1 && (Co == 32 || Co == 64) && W % 4 == 0 && H >= 6 && Hp > 0 && Wp > 0))
     return false;
-  const size_t fwd = (size_t)Ci * 6 * c0_round_stride(W, 16) * 4;
+  const size_t fwd = (size_t)Ci * C0_PR * c0_round_stride(W, 16) * 4;
   const int rs = c0_round_stride(W, 11);
   int plane = 4 * rs;
   while (plane % 32 != 3) ++plane;
@@ -251,8 +261,8 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
   VQA_REQUIRE(c0_supported(Ci, H, W, Co, 1), "vqa_conv0_relu_pool_fwd: unsupported shape Ci=%d H=%d W=%d Co=%d", Ci, H, W, Co);
   VQA_REQUIRE(((uintptr_t)x_nchw % 16) == 0, "vqa_conv0_relu_pool_fwd: input must be 16-byte aligned");
   const int Hp = (H - 2) / 2, Wp = (W - 2) / 2, RS = c0_round_stride(W, 16);
-  const size_t lds = (size_t)Ci * 6 * RS * 4;
-  const dim3 grid((Hp + 1) / 2, B);
+  const size_t lds = (size_t)Ci * C0_PR * RS * 4;
+  const dim3 grid((Hp + C0_FR - 1) / C0_FR, B);
   C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_fwd_kernel<kCI, kTN>), grid, dim3(256), lds, (hipStream_t)stream,
                                               x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS));
   return check_hip(hipGetLastError(), "conv0_fwd launch");

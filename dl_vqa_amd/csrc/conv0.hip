@@ -36,7 +36,7 @@ constexpr int C0_FR = 4;
 constexpr int C0_PR = 2 * C0_FR + 2;
 
 template <int CI, int TN>
-__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* pooled, uint8_t* amax,
                                                         int H, int W, int Hp, int Wp, int RS) {
   extern __shared__ __attribute__((aligned(16))) float patch[];
@@ -86,15 +86,13 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
     const int px = wdx - __mul24(wr, Wp), j4 = l31 & 3;
     const float* ap = patch + __mul24(2 * wr + (j4 >> 1), RS) + 2 * px + (j4 & 1);
     f32x16 acc[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const float a = ap[koff[s]];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j)   // the first MFMA takes the constant 0 as C: no 16 v_mov per accumulator tile
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s][j], s == 0 ? zero : acc[j], 0, 0, 0);
     }
     const bool inner = 8 * t + 8 <= nwin;                       // uniform
     const uint32_t vl = (uint32_t)__mul24(8 * t + h, Co) + (uint32_t)l31;

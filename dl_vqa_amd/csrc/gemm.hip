@@ -236,6 +236,37 @@ __global__ void splitk_reduce_kernel(EpiParams pe, int splits) {
   }
 }
 
+// N % 4 == 0: a thread owns 4 consecutive columns, the slab reads are 16-byte loads issued four splits at a
+// time (the scalar version above is a chain of dependent 4-byte loads: 16 us for an 8-split 256 x 1024 output).
+// The summation order over the splits is the same as in the scalar kernel.
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(EpiParams pe, int splits) {
+  const int64_t total4 = (int64_t)pe.M * pe.N / 4;
+  const int n4 = pe.N / 4;
+  const float4* slab = reinterpret_cast<const float4*>(pe.slab);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+      const float4 a = slab[(int64_t)s * total4 + e], b = slab[(int64_t)(s + 1) * total4 + e];
+      const float4 c = slab[(int64_t)(s + 2) * total4 + e], d = slab[(int64_t)(s + 3) * total4 + e];
+      v.x = (((v.x + a.x) + b.x) + c.x) + d.x; v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+      v.z = (((v.z + a.z) + b.z) + c.z) + d.z; v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; s < splits; ++s) {
+      const float4 a = slab[(int64_t)s * total4 + e];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    const int row = (int)(e / n4), col = 4 * (int)(e - (int64_t)row * n4);
+    const float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (pe.aux) pe.aux[(int64_t)row * pe.ldc + col + k] = r[k];
+      pe.C[(int64_t)row * pe.ldc + col + k] = epi_apply(pe, r[k], row, col + k);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ host side
 struct GemmPlan { int big; int tiles_m, tiles_n, nk, splits, ks_per_split, order; };
 
@@ -420,10 +451,12 @@ int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ld
                   : dispatch_gemm<Cfg64>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s);
     if (rc) return rc;
     if (p.splits > 1) {
-      const int64_t total = (int64_t)M * N;
+      const bool vec = N % 4 == 0;
+      const int64_t total = (int64_t)M * N / (vec ? 4 : 1);
       int blocks = (int)((total + 255) / 256);
       if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, pe, p.splits);
+      if (vec) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, s, pe, p.splits);
+      else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, pe, p.splits);
       rc = check_hip(hipGetLastError(), "splitk_reduce launch");
     }
   }

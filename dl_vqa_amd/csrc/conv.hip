@@ -46,11 +46,12 @@ static int set_smem(K kern, int bytes, const char* what) {
 template <class Cfg, bool U>
 static int launch_fwd(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* amax,
                       const ConvGeom& g, hipStream_t s) {
+  using SL = SmemLayout<Cfg, true, false>;
   const int nWin = g.B * g.Hp * g.Wp, K = 9 * g.CiP;
   typename ConvFwdA<Cfg::NVA, Cfg::LT, U>::Params pa{x, g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
   typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wf, g.Co, g.Co, K};
   const int tiles_m = (4 * nWin + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.Co + Cfg::BN - 1) / Cfg::BN;
-  const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2), tiles = tiles_m * tiles_n;
+  const int slots = 256 * SL::WG_PER_CU, tiles = tiles_m * tiles_n;
   const char* pt = getenv("VQA_PERSISTENT");
   // Persistent tiles measured neutral to slower on the conv kernels (conv1 fwd 3.83 -> 3.81 ms, conv2 dgrad
   // 3.65 -> 3.93 ms: their K loops are long and the second workgroup / MFMA wave of the SIMD already covers a
@@ -59,15 +60,15 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   if (persistent) {
     auto pk = conv_fwd_persistent_kernel<typename Cfg::Persistent, U>;
     static bool done2 = false;
-    if (!done2) { int rc = set_smem(pk, Cfg::SMEM_BYTES, "attr(conv_fwd_p)"); if (rc) return rc; done2 = true; }
-    hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, bias,
+    if (!done2) { int rc = set_smem(pk, SL::BYTES, "attr(conv_fwd_p)"); if (rc) return rc; done2 = true; }
+    hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, bias,
                        pooled, amax, g.Co, tiles_m, tiles_n, (K + BK - 1) / BK);
     return check_hip(hipGetLastError(), "conv_fwd_persistent launch");
   }
   auto kern = conv_fwd_kernel<Cfg, U>;
   static bool done = false;
-  if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_fwd)"); if (rc) return rc; done = true; }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, bias, pooled, amax,
+  if (!done) { int rc = set_smem(kern, SL::BYTES, "attr(conv_fwd)"); if (rc) return rc; done = true; }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, bias, pooled, amax,
                      g.Co, tiles_m, tiles_n, (K + BK - 1) / BK);
   return check_hip(hipGetLastError(), "conv_fwd launch");
 }
@@ -75,25 +76,26 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
 template <class Cfg, bool U>
 static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, float* dx, const ConvGeom& g,
                         hipStream_t s) {
+  using SL = SmemLayout<Cfg, true, false>;
   const int rows = g.B * g.H * g.W, K = 9 * g.Co;
   typename ConvDgradA<Cfg::NVA, Cfg::LT, U>::Params pa{dp, am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
   typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wd, g.CiP, g.CiP, K};
   const int tiles_m = (rows + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.CiP + Cfg::BN - 1) / Cfg::BN;
-  const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2), tiles = tiles_m * tiles_n;
+  const int slots = 256 * SL::WG_PER_CU, tiles = tiles_m * tiles_n;
   const char* pt = getenv("VQA_PERSISTENT");
   const bool persistent = pt && pt[0] == '1';   // see launch_fwd
   if (persistent) {
     auto pk = conv_dgrad_persistent_kernel<typename Cfg::Persistent, U>;
     static bool done2 = false;
-    if (!done2) { int rc = set_smem(pk, Cfg::SMEM_BYTES, "attr(conv_dgrad_p)"); if (rc) return rc; done2 = true; }
-    hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, dx,
+    if (!done2) { int rc = set_smem(pk, SL::BYTES, "attr(conv_dgrad_p)"); if (rc) return rc; done2 = true; }
+    hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, dx,
                        g.CiP, tiles_m, tiles_n, (K + BK - 1) / BK);
     return check_hip(hipGetLastError(), "conv_dgrad_persistent launch");
   }
   auto kern = conv_dgrad_kernel<Cfg, U>;
   static bool done = false;
-  if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_dgrad)"); if (rc) return rc; done = true; }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, dx, g.CiP, tiles_m,
+  if (!done) { int rc = set_smem(kern, SL::BYTES, "attr(conv_dgrad)"); if (rc) return rc; done = true; }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, dx, g.CiP, tiles_m,
                      tiles_n, (K + BK - 1) / BK);
   return check_hip(hipGetLastError(), "conv_dgrad launch");
 }
@@ -125,13 +127,14 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
 template <class Cfg, bool U>
 static int launch_wgrad(const float* x, const float* dp, const uint8_t* am, float* slab, float* bias_slab,
                         const ConvGeom& g, const WgradPlan& p, hipStream_t s) {
+  using SL = SmemLayout<Cfg, false, false>;
   WgradGeom wg{g.H, g.W, g.CiP, g.Hp, g.Wp, g.Co, g.stride, p.Mtot};
   typename WgradA<Cfg::NVA, Cfg::LT, U>::Params pa{x, wg, p.KI};
   typename WgradB<Cfg::NVB, Cfg::LT, U>::Params pb{dp, am, wg};
   auto kern = conv_wgrad_kernel<Cfg, U>;
   static bool done = false;
-  if (!done) { int rc = set_smem(kern, Cfg::SMEM_BYTES, "attr(conv_wgrad)"); if (rc) return rc; done = true; }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, slab,
+  if (!done) { int rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad)"); if (rc) return rc; done = true; }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, slab,
                      bias_slab, p.tiles_m, p.tiles_n, p.nk, p.ks_per_split);
   return check_hip(hipGetLastError(), "conv_wgrad launch");
 }

@@ -319,6 +319,7 @@ static GemmPlan plan_gemm(int M, int N, int K) {
 template <class Cfg, class AL, class BL>
 static int launch_gemm(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
                        const GemmPlan& p, int K, hipStream_t s) {
+  using SL = SmemLayout<Cfg, AL::kTypeR, BL::kTypeR>;
   if constexpr (Cfg::BM * Cfg::BN > 64 * 64) {
     // Persistent tiles pay when K is short (<= 16 K-steps: dispatch + prologue + epilogue are then a large
     // share of a tile's life: v_conv forward 1.13 -> 1.04 ms, LSTM input GEMM 0.116 -> 0.105 ms); with long K
@@ -331,14 +332,14 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
       auto pk = gemm_persistent_kernel<typename Cfg::Persistent, AL, BL>;
       if (!attr2) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SL::BYTES),
                            "hipFuncSetAttribute(gemm_persistent)");
         if (rc) return rc;
         attr2 = true;
       }
-      const int slots = 256 * (Cfg::SMEM_BYTES > 80 * 1024 ? 1 : 2);
+      const int slots = 256 * SL::WG_PER_CU;
       const int tiles = p.tiles_m * p.tiles_n;
-      hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, pe,
+      hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, pe,
                          p.tiles_m, p.tiles_n, p.nk, K, p.order);
       return check_hip(hipGetLastError(), "gemm_persistent_kernel launch");
     }
@@ -347,13 +348,13 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
   auto kern = gemm_kernel<Cfg, AL, BL>;
   if (!attr_done) {
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SL::BYTES),
                        "hipFuncSetAttribute(gemm)");
     if (rc) return rc;
     attr_done = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n * p.splits);
-  hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), Cfg::SMEM_BYTES, s, pa, pb, pe, p.tiles_m, p.tiles_n, p.nk,
+  hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, pe, p.tiles_m, p.tiles_n, p.nk,
                      p.ks_per_split, K, p.order, p.splits);
   return check_hip(hipGetLastError(), "gemm_kernel launch");
 }

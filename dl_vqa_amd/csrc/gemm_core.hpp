@@ -62,8 +62,8 @@ struct TileCfg {
   static constexpr int NVA = BM * 8 / LT, NVB = BN * 8 / LT;  // float4 per loader thread per K-step
   // One LDS buffer per operand per stage.  Its image depends on the operand's loader type (LdsImage):
   // both forms fit in 36 floats per row/column of the tile.
-  static constexpr int ABUF = 36 * BM, BBUF = 36 * BN;      // floats
-  static constexpr int SMEM_FLOATS = 2 * (ABUF + BBUF);
+  static constexpr int ABUF_MAX = 36 * BM, BBUF_MAX = 36 * BN;      // floats, upper bound (SmemLayout has the exact sizes)
+  static constexpr int SMEM_FLOATS = 2 * (ABUF_MAX + BBUF_MAX);
   static constexpr int SMEM_BYTES = SMEM_FLOATS * 4;
   // waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
   // two 512-thread workgroups per CU (4 waves/SIMD, <= 128 VGPRs) up to 128x128, one above that
@@ -90,6 +90,17 @@ struct TileCfg {
 // Both are conflict-free, and both need 4x fewer LDS write instructions than a transposing b32 image.
 constexpr int LDS_RS = 36;
 template <int TILE> struct LdsImage { static constexpr int CS = TILE + 4; };
+// Exact LDS footprint of a tile for the operand types in use (floats per stage / bytes in total); a type C
+// image is smaller than 36 * TILE.  (A = R, B = C 128x64 tiles take 54272 bytes and 79 VGPRs, enough for
+// three workgroups per CU; with the launch bounds asking for 6 waves per SIMD conv1 dgrad ran 16 % SLOWER,
+// 4.67 against 4.03 ms on the same box, so the kernels keep asking for two.)
+template <class Cfg, bool AR, bool BR>
+struct SmemLayout {
+  static constexpr int ABUF = AR ? LDS_RS * Cfg::BM : BK * LdsImage<Cfg::BM>::CS;
+  static constexpr int BBUF = BR ? LDS_RS * Cfg::BN : BK * LdsImage<Cfg::BN>::CS;
+  static constexpr int BYTES = 2 * (ABUF + BBUF) * 4;
+  static constexpr int WG_PER_CU = BYTES > 80 * 1024 ? 1 : 2;   // resident workgroups
+};
 
 // Loader thread -> staging coordinates, for LT = 256 or 512 loader threads (8 lanes = one 128-B line).
 //   type R: rows (ltid >> 3) + (LT/8)*p, k-chunk ltid & 7 (k = 4*chunk .. +3)
@@ -324,9 +335,10 @@ template <class Cfg> __device__ __forceinline__ int loader_tid() { return (threa
 template <class Cfg, class AL, class BL>
 __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, float* smem) {
   constexpr int D = Cfg::PREFETCH;
+  using SL = SmemLayout<Cfg, AL::kTypeR, BL::kTypeR>;
   const int ltid = loader_tid<Cfg>();
   float* const As0 = smem;
-  float* const Bs0 = smem + 2 * Cfg::ABUF;
+  float* const Bs0 = smem + 2 * SL::ABUF;
   typename AL::Raw rawA[D];
   typename BL::Raw rawB[D];
   if (VQA_PRIO_LOADER) __builtin_amdgcn_s_setprio(VQA_PRIO_LOADER);
@@ -350,8 +362,8 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
         const int nxt = ((ks + d - ks0) & 1) ^ 1;
 #ifdef VQA_DIAG
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * Cfg::ABUF, ltid);
-        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * Cfg::BBUF, ltid);
+        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid);
+        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         al.issue(ks + d + 1 + D, rawA[d]);
@@ -367,9 +379,9 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
         bl.issue(ks + d + 1 + D, rawB[d]);
         __syncthreads();
 #else
-        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * Cfg::ABUF, ltid);
+        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid);
         al.issue(ks + d + 1 + D, rawA[d]);
-        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * Cfg::BBUF, ltid);
+        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid);
         bl.issue(ks + d + 1 + D, rawB[d]);
         __syncthreads();
 #endif
@@ -388,10 +400,11 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
 template <class Cfg, bool AR, bool BR, bool SHORT_TAIL>
 __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1, int Ktot,
                                           const float* smem) {
+  using SL = SmemLayout<Cfg, AR, BR>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const float* const As0 = smem;
-  const float* const Bs0 = smem + 2 * Cfg::ABUF;
+  const float* const Bs0 = smem + 2 * SL::ABUF;
   __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);   // MFMA waves win issue arbitration over the loader waves of their SIMD
 #ifdef VQA_DIAG
   unsigned long long t_mma = 0, t_bar = 0;
@@ -400,8 +413,8 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
   __syncthreads();
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;
-    const float* const Ac = As0 + cur * Cfg::ABUF;
-    const float* const Bc = Bs0 + cur * Cfg::BBUF;
+    const float* const Ac = As0 + cur * SL::ABUF;
+    const float* const Bc = Bs0 + cur * SL::BBUF;
 #ifdef VQA_DIAG
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -460,13 +473,14 @@ template <class Cfg, class AL, class BL, bool SHORT_TAIL, class InitTile, class 
 __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntiles, int nk, int Ktot, float* smem,
                                                 InitTile&& init_tile, Epilogue&& epilogue) {
   static_assert(Cfg::PREFETCH == 1, "persistent tiles need a single Raw register set");
+  using SL = SmemLayout<Cfg, AL::kTypeR, BL::kTypeR>;
   if (first >= ntiles) return;
   const int my_tiles = (ntiles - first + stride - 1) / stride;
   const int total = my_tiles * nk;
   if (is_loader_wave<Cfg>()) {
     const int ltid = loader_tid<Cfg>();
     float* const As0 = smem;
-    float* const Bs0 = smem + 2 * Cfg::ABUF;
+    float* const Bs0 = smem + 2 * SL::ABUF;
     AL al; BL bl;
     typename AL::Raw rawA;
     typename BL::Raw rawB;
@@ -489,8 +503,8 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
     __syncthreads();
     for (int s = 0; s < total; ++s) {
       const int nxt = (s & 1) ^ 1;
-      stage_store_one<Cfg, AL, true>(al, rawA, As0 + nxt * Cfg::ABUF, ltid);
-      stage_store_one<Cfg, BL, false>(bl, rawB, Bs0 + nxt * Cfg::BBUF, ltid);
+      stage_store_one<Cfg, AL, true>(al, rawA, As0 + nxt * SL::ABUF, ltid);
+      stage_store_one<Cfg, BL, false>(bl, rawB, Bs0 + nxt * SL::BBUF, ltid);
       next();
       __syncthreads();
     }
@@ -499,7 +513,7 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const float* const As0 = smem;
-  const float* const Bs0 = smem + 2 * Cfg::ABUF;
+  const float* const Bs0 = smem + 2 * SL::ABUF;
   __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
   __syncthreads();
   int s = 0;
@@ -512,8 +526,8 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int ks = 0; ks < nk; ++ks, ++s) {
-      const float* const Ac = As0 + (s & 1) * Cfg::ABUF;
-      const float* const Bc = Bs0 + (s & 1) * Cfg::BBUF;
+      const float* const Ac = As0 + (s & 1) * SL::ABUF;
+      const float* const Bc = Bs0 + (s & 1) * SL::BBUF;
       if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, AL::kTypeR, BL::kTypeR, 1>(Ac, Bc, acc, wm, wn, lane);
       else mma_steps<Cfg, AL::kTypeR, BL::kTypeR, 4>(Ac, Bc, acc, wm, wn, lane);
       __syncthreads();

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "vqa_relu_drop_bwd": (i32, [f32p, f32p, f32p, i64, f32, u64, vp]),
     "vqa_add2d": (i32, [f32p, i64, f32p, i64, f32p, i64, i64, i32, vp]),
     "vqa_scale_by": (i32, [f32p, i64, f32p, vp]),
+    "vqa_half_to_float": (i32, [vp, f32p, i64, vp]),
     "vqa_adam": (i32, [f32p, f32p, f32p, f32p, i64, f32, f32, f32, f32, i32, f32, vp]),
 }
 

@@ -1,6 +1,7 @@
 // Memory-bound stages of the VQA hot path: dropout, L2-norm, embedding+tanh, LSTM cell, attention
 // score / softmax / weighted sum, soft-target cross entropy, reductions, Adam.
 // All are HBM-bound streaming kernels: 16-byte per-lane accesses, wave64 shuffles for reductions.
+#include <hip/hip_fp16.h>
 #include "common.hpp"
 
 namespace vqa {
@@ -564,6 +565,19 @@ __global__ void add2d_kernel(const float* a, int64_t lda, const float* b, int64_
   }
 }
 
+// fp16 -> fp32, 8 values (16 bytes in, 32 bytes out) per thread and iteration
+__global__ void half_to_float_kernel(const __half* x, float* y, int64_t n) {
+  const int64_t n8 = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 raw = reinterpret_cast<const uint4*>(x)[i];
+    const __half2* h = reinterpret_cast<const __half2*>(&raw);
+    const float2 a = __half22float2(h[0]), b = __half22float2(h[1]), c = __half22float2(h[2]), d = __half22float2(h[3]);
+    reinterpret_cast<float4*>(y)[2 * i] = make_float4(a.x, a.y, b.x, b.y);
+    reinterpret_cast<float4*>(y)[2 * i + 1] = make_float4(c.x, c.y, d.x, d.y);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - 8 * n8) y[8 * n8 + threadIdx.x] = __half2float(x[8 * n8 + threadIdx.x]);
+}
+
 __global__ void scale_by_kernel(float* x, int64_t n, const float* s) {
   const float k = *s;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= k;
@@ -752,6 +766,14 @@ int vqa_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y
   hipLaunchKernelGGL(add2d_kernel, dim3(grid_for(rows * cols, 256)), dim3(256), 0, STREAM, a, lda, b, ldb, y, ldy,
                      rows, cols);
   return check_hip(hipGetLastError(), "add2d launch");
+}
+
+int vqa_half_to_float(const void* x_f16, float* y, int64_t n, vqa_stream_t stream) {
+  VQA_REQUIRE(x_f16 && y && n > 0, "vqa_half_to_float: bad args");
+  VQA_REQUIRE(((uintptr_t)x_f16 % 16) == 0 && ((uintptr_t)y % 16) == 0, "vqa_half_to_float: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(half_to_float_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, STREAM,
+                     static_cast<const __half*>(x_f16), y, n);
+  return check_hip(hipGetLastError(), "half_to_float launch");
 }
 
 int vqa_scale_by(float* x, int64_t n, const float* scalar, vqa_stream_t stream) {

@@ -225,6 +225,10 @@ class VqaNet(nn.Module):
         self._ensure_flat()
         if not v.is_cuda:
             raise RuntimeError("dl_vqa_amd.VqaNet.forward needs CUDA (HIP) tensors; there is no CPU fallback")
+        if v.dtype == torch.float16:
+            # the dataset's storage format (preprocessing/preprocess_images.py:39-53): widen on the device
+            from . import ops
+            v = ops.half_to_float(v.contiguous())
         seed = self._next_seed() if self.training else 0
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._params)
         if need_grad:

@@ -251,6 +251,15 @@ def add(a, b, out):
     return add2d(a, a.numel(), b, a.numel(), out, a.numel(), 1, a.numel())
 
 
+def half_to_float(x: torch.Tensor) -> torch.Tensor:
+    """fp16 image features -> fp32 on the device, layout unchanged (reference: host-side cast in
+    preprocessing/data_preprocessing.py:167-176)."""
+    assert x.dtype == torch.float16 and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call("vqa_half_to_float", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
 def scale_by(x, scalar_dev):
     call("vqa_scale_by", ptr(x), x.numel(), ptr(scalar_dev), stream())
     return x

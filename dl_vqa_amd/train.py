@@ -75,8 +75,10 @@ def run_batch(model, log_softmax, batch_data, max_answers, batch_divisor: Option
     a_indices = a_indices.to(dev, non_blocking=True)
     a_values = a_values.to(dev, non_blocking=True)
     q_len = q_len.to(dev, non_blocking=True)
-    if v.dtype != torch.float32:
-        v = v.float()                      # the dataset stores fp16 features (data_preprocessing.py:174)
+    # the dataset stores fp16 features (data_preprocessing.py:174 casts them on the host, per sample): the fp16
+    # batch goes over PCIe as is and VqaNet.forward widens it on the device (vqa_half_to_float)
+    if v.dtype not in (torch.float32, torch.float16):
+        v = v.float()
     y_hat = model(v, q, q_len)
     batch_loss, batch_score = soft_ce_loss_and_score(y_hat, a_indices, a_values, batch_divisor)
     return batch_loss, batch_score

@@ -186,6 +186,13 @@ int vqa_add2d(const float* a, int64_t lda, const float* b, int64_t ldb, float* y
 /* x[i] *= *scalar (scalar is a DEVICE pointer): chains an upstream loss gradient without a host sync */
 int vqa_scale_by(float* x, int64_t n, const float* scalar, vqa_stream_t stream);
 
+/* ---- input pipeline ----------------------------------------------------- */
+/* y[i] = (float)x[i] for n IEEE half values: the dataset stores image features as fp16 [N,3,S,S]
+ * (preprocessing/preprocess_images.py:39-53) and the reference casts them to fp32 on the HOST per sample
+ * (preprocessing/data_preprocessing.py:167-176); here the fp16 batch is uploaded as is (half the PCIe bytes)
+ * and widened on the device.  x and y 16-byte aligned or n small; layout unchanged (NCHW). */
+int vqa_half_to_float(const void* x_f16, float* y, int64_t n, vqa_stream_t stream);
+
 /* ---- optimiser: torch.optim.Adam defaults over one flat buffer (train.py:55,80) ------------- */
 int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
              float beta1, float beta2, float eps, int step, float grad_scale, vqa_stream_t stream);

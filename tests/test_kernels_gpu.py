@@ -121,6 +121,18 @@ def test_gemm_epilogue_tall_rowgroups_and_aux(M_groups, P, N):
         check(f"gemm aux P={P} op={op}", aux, acc, 1e-5)
 
 
+@pytest.mark.parametrize("n", [8, 37, 3 * 224 * 224 * 2 + 5])
+def test_half_to_float(n):
+    """fp16 image features are widened on the device; exact for every half value."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, generator=g) * 3).half()
+    x[: min(n, 6)] = torch.tensor([0.0, -0.0, 65504.0, -65504.0, 6e-8, float("inf")])[: min(n, 6)].half()
+    y = ops.half_to_float(x.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x.float())
+
+
 def test_gemm_rejects_misaligned():
     from dl_vqa_amd._lib import VqaHipError
     ops = _ops()

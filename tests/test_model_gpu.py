@@ -83,6 +83,21 @@ def test_golden_forward_loss_grads(name):
     assert float(dict(m.named_parameters())["text.embedding.weight"].grad[0].abs().max()) == 0.0
 
 
+def test_fp16_image_features_are_widened_on_the_device():
+    """the dataset stores fp16 image features; VqaNet.forward takes them as they are and
+    vqa_half_to_float widens them on the device: same logits, bit for bit, as a host-side .float()."""
+    g = Golden("tiny_plus")
+    m = build(tiny_cfg(g.meta), g.meta["V"], g.sd).eval()
+    v16 = g.t["v"].half()
+    q, ql = g.t["q"].to(DEV), g.t["q_len"].to(DEV)
+    with torch.no_grad():
+        y16 = m(v16.to(DEV), q, ql)
+        y32 = m(v16.float().to(DEV), q, ql)
+    torch.cuda.synchronize()
+    assert torch.equal(y16, y32)
+    assert float((y16.cpu() - g.t["logits"]).abs().max()) < 5e-2      # fp16 rounding of the input only
+
+
 def test_full224_reference_logits_and_gradients():
     """North-star architecture at S=224, B=2: parameters re-created from the seed, logits and
     gradient checksums compared with what the reference produced (tests/golden/make_golden.py)."""

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
     "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
     "vqa_lstm_cell_bwd": (i32, [f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, i32, i32, vp]),
+    "vqa_lstm_step_supported": (i32, [i32]),
+    "vqa_lstm_step_fwd": (i32, [f32p, f32p, f32p, f32p, vp, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
     "vqa_att_score_fwd": (i32, [f32p, f32p, i32, f32p, f32p, i32, i32, i32, i32, f32, u64, f32p, vp]),
     "vqa_att_row_splits": (i32, [i32]),
     "vqa_att_score_bwd": (i32, [f32p, f32p, i32, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, i32, f32p, f32p, vp]),

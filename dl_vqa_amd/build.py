@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvqa_hip.so")
-SOURCES = ["gemm.hip", "conv.hip", "conv0.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "conv.hip", "conv0.hip", "lstm.hip", "elementwise.hip"]
 HEADERS = ["common.hpp", "gemm_core.hpp", "conv_device.inc", os.path.join("..", "..", "include", "vqa_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

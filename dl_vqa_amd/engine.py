@@ -133,14 +133,20 @@ class Engine:
             Hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=dev)
             Cs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=dev)
             gates = new(T, B, 4 * H)
-            hg = new(B, 4 * H)
+            fused = ops.lstm_step_supported(H) and os.environ.get("VQA_FUSED_LSTM", "1") == "1"
+            hg = None if fused else new(B, 4 * H)
             order = range(T) if d == 0 else range(T - 1, -1, -1)
             for n, t in enumerate(order):
                 si, so = (t, t + 1) if d == 0 else (t + 1, t)
-                ops.gemm(Hs[si], w_hh, hg, B, 4 * H, H, tag=11)
                 last = n == T - 1
-                ops.lstm_cell_fwd(xg[t * B:(t + 1) * B], hg, Cs[si], Hs[si], q_len, t, gates[t], Cs[so], Hs[so],
-                                  combined[:, GC + d * H:] if last else None, Dc)
+                cf = combined[:, GC + d * H:] if last else None
+                if fused:   # recurrent GEMM with the cell as its epilogue: one launch per step
+                    ops.lstm_step_fwd(Hs[si], w_hh, xg[t * B:(t + 1) * B], Cs[si], q_len, t, gates[t], Cs[so], Hs[so],
+                                      cf, Dc)
+                else:
+                    ops.gemm(Hs[si], w_hh, hg, B, 4 * H, H, tag=11)
+                    ops.lstm_cell_fwd(xg[t * B:(t + 1) * B], hg, Cs[si], Hs[si], q_len, t, gates[t], Cs[so], Hs[so],
+                                      cf, Dc)
             lstm[d] = SimpleNamespace(gates=gates, Hs=Hs, Cs=Cs, xg=xg, hg=hg)
 
         # The question branch is a chain of small (M = B) launches, independent of the image branch until the

@@ -162,6 +162,17 @@ def lstm_cell_fwd(xg_t, hg, c_in, h_in, q_len, t, gates, c_out, h_out, c_final=N
          ptr(h_out), ptr(c_final), cf_ld, B, H, stream())
 
 
+def lstm_step_supported(H: int) -> bool:
+    return bool(_lib.load().vqa_lstm_step_supported(H))
+
+
+def lstm_step_fwd(h_in, w_hh, xg_t, c_in, q_len, t, gates, c_out, h_out, c_final=None, cf_ld=0):
+    """One fused recurrent step: h_in @ w_hh.T on the MFMA engine + the LSTM cell as its epilogue."""
+    B, H = c_in.shape
+    call("vqa_lstm_step_fwd", ptr(h_in), ptr(w_hh), ptr(xg_t), ptr(c_in), ptr(q_len), t, ptr(gates), ptr(c_out),
+         ptr(h_out), ptr(c_final), cf_ld, B, H, stream())
+
+
 def lstm_cell_bwd(gates, c_in, c_out, q_len, t, dh, dc, dgates):
     B, H = c_in.shape
     call("vqa_lstm_cell_bwd", ptr(gates), ptr(c_in), ptr(c_out), ptr(q_len), t, ptr(dh), ptr(dc), ptr(dgates),

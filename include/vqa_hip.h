@@ -134,6 +134,16 @@ int vqa_lstm_cell_fwd(const float* xg, const float* hg, const float* c_in, const
 int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out, const int64_t* q_len,
                       int t, float* dh, float* dc, float* dgates, int B, int H, vqa_stream_t stream);
 
+/* Fused recurrent step (models/model.py:145-149, 159-164): h_in W_hh^T on the MFMA engine with the cell as its
+ * epilogue -- replaces vqa_gemm(h_in, w_hh -> hg) + vqa_lstm_cell_fwd for one time step and direction.
+ *   h_in [B][H], w_hh [4H][H] (PyTorch gate order i,f,g,o), xg_t [B][4H] = x_t W_ih^T + b_ih + b_hh,
+ *   c_in [B][H], q_len [B] int64 (sample b advances only while t < q_len[b]); outputs as vqa_lstm_cell_fwd.
+ * Requires H % 32 == 0 (vqa_lstm_step_supported); other sizes use the unfused pair. */
+int vqa_lstm_step_supported(int H);
+int vqa_lstm_step_fwd(const float* h_in, const float* w_hh, const float* xg_t, const float* c_in,
+                      const int64_t* q_len, int t, float* gates, float* c_out, float* h_out, float* c_final,
+                      int64_t cf_ld, int B, int H, vqa_stream_t stream);
+
 /* ---- attention (models/model.py:169-195 Attention, 208-221 image_question_attention) ---------
  * x = relu(v' (+|*) q') comes from vqa_gemm(rowgroup = q') as xs[m][n]; for do_option '|' (model.py:192)
  * x = relu(cat[v', tile(q')]) has 2*mid channels: xs holds the v' half and qcat = q' [B][mid] the other.

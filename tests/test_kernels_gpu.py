@@ -284,6 +284,42 @@ def test_lstm_cell_fwd_bwd():
     check("lstm cell dh passthrough", dhd, hr.grad, 5e-6)
 
 
+@pytest.mark.parametrize("B,H,t", [(6, 32, 2), (70, 64, 0), (256, 1024, 5), (130, 96, 3)])
+def test_lstm_fused_step_matches_gemm_plus_cell(B, H, t):
+    """vqa_lstm_step_fwd (recurrent GEMM with the cell as its epilogue) against fp64 math and, bit for bit on the
+    states, against the unfused pair vqa_gemm + vqa_lstm_cell_fwd it replaces."""
+    ops = _ops()
+    assert ops.lstm_step_supported(H) and not ops.lstm_step_supported(20)
+    g = torch.Generator().manual_seed(B + H)
+    q_len = torch.randint(1, 8, (B,), generator=g)
+    w_hh = torch.randn(4 * H, H, generator=g) / math.sqrt(H)
+    xg = torch.randn(B, 4 * H, generator=g)
+    c0, h0 = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+    pre = xg.double() + h0.double() @ w_hh.double().t()
+    i, f, gg, o = pre.split(H, dim=1)
+    cn = torch.sigmoid(f) * c0.double() + torch.sigmoid(i) * torch.tanh(gg)
+    hn = torch.sigmoid(o) * torch.tanh(cn)
+    m = (q_len > t).double().unsqueeze(1)
+    c1, h1 = m * cn + (1 - m) * c0.double(), m * hn + (1 - m) * h0.double()
+    gref = m * torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)], dim=1)
+
+    d = lambda x: x.to(DEV)
+    new = lambda *s_: torch.full(s_, 9.0, device=DEV)
+    gates, c_out, h_out, cf = new(B, 4 * H), new(B, H), new(B, H), torch.zeros(B, 2 * H + 4, device=DEV)
+    ops.lstm_step_fwd(d(h0), d(w_hh), d(xg), d(c0), d(q_len), t, gates, c_out, h_out, cf[:, 4:], 2 * H + 4)
+    hg, gates2, c2, h2 = new(B, 4 * H), new(B, 4 * H), new(B, H), new(B, H)
+    ops.gemm(d(h0), d(w_hh), hg, B, 4 * H, H)
+    ops.lstm_cell_fwd(d(xg), hg, d(c0), d(h0), d(q_len), t, gates2, c2, h2, None, 0)
+    torch.cuda.synchronize()
+    check("fused lstm c", c_out, c1, 5e-6)
+    check("fused lstm h", h_out, h1, 5e-6)
+    check("fused lstm gates", gates, gref, 5e-6)
+    check("fused lstm c_final", cf[:, 4:4 + H], c1, 5e-6)
+    assert float(cf[:, :4].abs().max()) == 0.0 and float(cf[:, 4 + H:].abs().max()) == 0.0
+    assert float((c_out - c2).abs().max()) < 2e-6 and float((h_out - h2).abs().max()) < 2e-6
+    assert float((gates - gates2).abs().max()) < 2e-6
+
+
 def test_attention_score_and_apply():
     ops = _ops()
     g = torch.Generator().manual_seed(8)

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build_var/$name
-for f in gemm conv conv0 elementwise; do
+for f in gemm conv conv0 lstm elementwise; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -w "$@" -c dl_vqa_amd/csrc/$f.hip -o build_var/$name/$f.o &
 done
 wait

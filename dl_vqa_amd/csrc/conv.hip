@@ -58,7 +58,7 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   // tile's prologue and epilogue), so they are opt-in (VQA_PERSISTENT=1) and parity-tested that way.
   const bool persistent = pt && pt[0] == '1';
   if (persistent) {
-    auto pk = conv_fwd_persistent_kernel<typename Cfg::Persistent, U>;
+    auto pk = conv_fwd_persistent_kernel<Cfg, U>;
     static bool done2 = false;
     if (!done2) { int rc = set_smem(pk, SL::BYTES, "attr(conv_fwd_p)"); if (rc) return rc; done2 = true; }
     hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, bias,
@@ -85,7 +85,7 @@ static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, flo
   const char* pt = getenv("VQA_PERSISTENT");
   const bool persistent = pt && pt[0] == '1';   // see launch_fwd
   if (persistent) {
-    auto pk = conv_dgrad_persistent_kernel<typename Cfg::Persistent, U>;
+    auto pk = conv_dgrad_persistent_kernel<Cfg, U>;
     static bool done2 = false;
     if (!done2) { int rc = set_smem(pk, SL::BYTES, "attr(conv_dgrad_p)"); if (rc) return rc; done2 = true; }
     hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, dx,

@@ -329,7 +329,7 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
     const bool persistent = pt ? pt[0] == '1' : p.nk <= 16;
     if (p.splits == 1 && persistent) {
       static bool attr2 = false;
-      auto pk = gemm_persistent_kernel<typename Cfg::Persistent, AL, BL>;
+      auto pk = gemm_persistent_kernel<Cfg, AL, BL>;
       if (!attr2) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SL::BYTES),

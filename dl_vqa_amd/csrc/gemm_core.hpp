@@ -464,16 +464,15 @@ __device__ __forceinline__ bool gemm_mainloop(Init&& init, Done&& done, f32x16 (
 // [0, nk).  The loader waves treat the tiles as one flat sequence of K-steps: while the MFMA waves run the
 // epilogue of tile t, the first K-step of tile t+1 is already in LDS and its second in registers, and no
 // workgroup is re-dispatched between tiles (a 128x128 tile with K = 256 lives only ~28 us, so dispatch +
-// prologue + epilogue per tile were a large part of it).  Requires Cfg::PREFETCH == 1: the loader
-// functor's state is re-initialised right before the first issue() of a new tile, after the last
-// finish() of the old one.
+// prologue + epilogue per tile were a large part of it).  The loader functors are re-initialised right
+// before the first issue() of a new tile.
 //   init_tile(tile, AL&, BL&)   : (re)initialise both loaders for a tile
 //   epilogue(tile, acc)         : MFMA waves only, no barriers inside
 template <class Cfg, class AL, class BL, bool SHORT_TAIL, class InitTile, class Epilogue>
 __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntiles, int nk, int Ktot, float* smem,
                                                 InitTile&& init_tile, Epilogue&& epilogue) {
-  static_assert(Cfg::PREFETCH == 1, "persistent tiles need a single Raw register set");
   using SL = SmemLayout<Cfg, AL::kTypeR, BL::kTypeR>;
+  constexpr int D = Cfg::PREFETCH;
   if (first >= ntiles) return;
   const int my_tiles = (ntiles - first + stride - 1) / stride;
   const int total = my_tiles * nk;
@@ -482,31 +481,40 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * SL::ABUF;
     AL al; BL bl;
-    typename AL::Raw rawA;
-    typename BL::Raw rawB;
+    // ring of D register sets, as loader_loop; finish() of every loader reads only the Raw set and
+    // thread constants, so re-initialising the loaders for the next tile while sets of the previous tile
+    // are still waiting to be stored is safe
+    typename AL::Raw rawA[D];
+    typename BL::Raw rawB[D];
     int tile = first, ks = 0;            // the K-step the next issue() fetches
     init_tile(tile, al, bl);
-    auto next = [&]() {                  // issue K-step (tile, ks) and advance the cursor across tile seams
+    auto next = [&](typename AL::Raw& ra, typename BL::Raw& rb) {   // issue K-step (tile, ks), advance across tile seams
       if (ks == nk) {
         ks = 0;
         if (tile + stride < ntiles) tile += stride;     // past the last tile: harmless refetch, never read
         init_tile(tile, al, bl);
       }
-      al.issue(ks, rawA);
-      bl.issue(ks, rawB);
+      al.issue(ks, ra);
+      bl.issue(ks, rb);
       ++ks;
     };
-    next();
-    stage_store_one<Cfg, AL, true>(al, rawA, As0, ltid);
-    stage_store_one<Cfg, BL, false>(bl, rawB, Bs0, ltid);
-    next();
+    next(rawA[0], rawB[0]);
+    stage_store_one<Cfg, AL, true>(al, rawA[0], As0, ltid);
+    stage_store_one<Cfg, BL, false>(bl, rawB[0], Bs0, ltid);
+#pragma unroll
+    for (int d = 0; d < D; ++d) next(rawA[d], rawB[d]);
     __syncthreads();
-    for (int s = 0; s < total; ++s) {
-      const int nxt = (s & 1) ^ 1;
-      stage_store_one<Cfg, AL, true>(al, rawA, As0 + nxt * SL::ABUF, ltid);
-      stage_store_one<Cfg, BL, false>(bl, rawB, Bs0 + nxt * SL::BBUF, ltid);
-      next();
-      __syncthreads();
+    for (int s = 0; s < total; s += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (s + d < total) {
+          const int nxt = ((s + d) & 1) ^ 1;
+          stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid);
+          stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid);
+          next(rawA[d], rawB[d]);
+          __syncthreads();
+        }
+      }
     }
     return;
   }

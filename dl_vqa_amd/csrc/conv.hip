@@ -32,7 +32,13 @@ using Cfg256x128 = TileCfg<256, 128, 4, 2>;   // 8 MFMA waves (64x64 each) + 4 l
 using Cfg256x64 = TileCfg<256, 64, 4, 2>;     // 8 MFMA waves (64x32 each)
 using Cfg64 = TileCfg<64, 64, 2, 2>;
 // wgrad rows are (tap, ci): 9*CiP = 576 for CiP = 64 is 4.5 x 128 but 6 x 96 (1 x 4 MFMA waves of 96x32)
-using Cfg96x128 = TileCfg<96, 128, 1, 4>;
+#ifndef VQA_WGRAD_PF
+#define VQA_WGRAD_PF 3
+#endif
+using Cfg96x128 = TileCfg<96, 128, 1, 4, 4, VQA_WGRAD_PF>;
+// wgrad streams new pixels from HBM every K-step: three K-steps of loads in flight (75 -> 78 % on conv1 in spite
+// of ~55 spilled loader registers; four spill 100+ and lose 15 points; dgrad's 128x64 tile loses 9 points at three)
+using Cfg128W = TileCfg<128, 128, 2, 2, 4, VQA_WGRAD_PF>;
 // the same tiles with 8 loader waves (1024 threads): two loader waves per SIMD for loader-bound K loops
 using Cfg256x128L8 = TileCfg<256, 128, 4, 2, 8>;
 using Cfg256x64L8 = TileCfg<256, 64, 4, 2, 8>;
@@ -249,8 +255,8 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
     const bool uni = CiP % BK == 0 && Co % BK == 0 && 2 * g.Wp >= BK;
     rc = p.bm == 96 ? (uni ? launch_wgrad<Cfg96x128, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
                            : launch_wgrad<Cfg96x128, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
-       : p.big ? (uni ? launch_wgrad<Cfg128, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
-                      : launch_wgrad<Cfg128, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
+       : p.big ? (uni ? launch_wgrad<Cfg128W, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
+                      : launch_wgrad<Cfg128W, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
                : (uni ? launch_wgrad<Cfg64, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
                       : launch_wgrad<Cfg64, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s));
     if (rc) return rc;

@@ -321,7 +321,13 @@ __device__ __forceinline__ void stage_store_one(const L& ld, const typename L::R
   constexpr int TILE = IS_A ? Cfg::BM : Cfg::BN;
   float4 r[NV];
   ld.finish(raw, r);
+#ifdef VQA_EXP_SKIP_STORE   // timing experiment: keep the global loads and finish(), drop the LDS writes
+#pragma unroll
+  for (int p = 0; p < NV; ++p) asm volatile("" ::"v"(r[p].x), "v"(r[p].y), "v"(r[p].z), "v"(r[p].w));
+  (void)dst; (void)ltid;
+#else
   if (L::kTypeR) lds_store_R<TILE, NV, Cfg::LT>(dst, r, ltid); else lds_store_C<TILE, NV, Cfg::LT>(dst, r, ltid);
+#endif
 }
 
 template <class Cfg> __device__ __forceinline__ bool is_loader_wave() { return threadIdx.x >= Cfg::MFMA_THREADS; }
@@ -374,9 +380,9 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
         t_st += t1 - t0; t_is += t2 - t1; t_ba += t3 - t2;
 #elif defined(VQA_EXP_SKIP_LOAD)   // timing experiments only: the MFMA side alone
         __syncthreads();
-#elif defined(VQA_EXP_SKIP_STORE)  // timing experiments only: global loads without the LDS stores
-        al.issue(ks + d + 1 + D, rawA[d]);
-        bl.issue(ks + d + 1 + D, rawB[d]);
+#elif defined(VQA_EXP_STORE_ONLY)  // timing experiments only: LDS stores of stale registers, no global loads
+        stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid);
+        stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid);
         __syncthreads();
 #else
         stage_store_one<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid);

@@ -228,7 +228,7 @@ int64_t vqa_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int CiP, int Co, 
   if (g.Hp <= 0 || g.Wp <= 0) return 0;
   const WgradPlan p = plan_wgrad(g);
   const int64_t slab = (int64_t)p.splits * p.KI * Co * 4;
-  const int64_t bias = (int64_t)p.splits * 4 * Co * 4;      // one partial bias row per (split, loader wave)
+  const int64_t bias = (int64_t)p.splits * Co * 4;          // one partial bias row per split
   return slab + bias;
 }
 
@@ -265,7 +265,7 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
     rc = check_hip(hipGetLastError(), "wgrad_reduce launch");
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bias_slab, dbias,
-                       p.splits * 4, Co);
+                       p.splits, Co);
     rc = check_hip(hipGetLastError(), "wgrad_bias_reduce launch");
   }
   return rc;

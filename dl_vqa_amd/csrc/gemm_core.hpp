@@ -267,9 +267,11 @@ struct PlainC {
 // allocation: accumulators + fragments for one, Raw tiles + addresses for the other, both <= 128 VGPRs.
 
 // NG groups of 4 k2-steps from one stage; the fragments of group t+1 are fetched before the MFMAs of group t.
-template <class Cfg, bool AR, bool BR, int NG>
+// CS: also accumulate the column sums of the B operand into cs[TN] (one value per lane = its column, over the
+// k the lane's fragments hold): the conv wgrad bias gradient, taken from fragments the wave reads anyway.
+template <class Cfg, bool AR, bool BR, int NG, bool CS = false>
 __device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x16 (&acc)[Cfg::TM][Cfg::TN],
-                                          int wm, int wn, int lane) {
+                                          int wm, int wn, int lane, float* cs = nullptr) {
   const int l31 = lane & 31, h = lane >> 5;
   constexpr int CSA = LdsImage<Cfg::BM>::CS, CSB = LdsImage<Cfg::BN>::CS;
   // group t, MFMA q: k = 8t + 4h + q
@@ -304,6 +306,12 @@ __device__ __forceinline__ void mma_steps(const float* As, const float* Bs, f32x
     const int cur = t & 1;
     if (t + 1 < NG) fetch(t + 1, cur ^ 1);
     __builtin_amdgcn_sched_barrier(0);   // reads of group t+1 stay above the MFMAs of group t
+    if (CS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) cs[j] += b[cur][q][j];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -403,9 +411,9 @@ __device__ __forceinline__ void loader_loop(AL& al, BL& bl, int ks0, int ks1, fl
 }
 
 // MFMA role.  SHORT_TAIL (conv0 forward, K = 36 = 32 + 4): the last K-step runs 4 k2-steps instead of 16.
-template <class Cfg, bool AR, bool BR, bool SHORT_TAIL>
+template <class Cfg, bool AR, bool BR, bool SHORT_TAIL, bool CS = false>
 __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1, int Ktot,
-                                          const float* smem) {
+                                          const float* smem, float* cs = nullptr) {
   using SL = SmemLayout<Cfg, AR, BR>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
@@ -425,8 +433,8 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
 #ifndef VQA_EXP_SKIP_MFMA   // timing experiments only (tools/build_variant.sh): results are garbage
-    if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, AR, BR, 1>(Ac, Bc, acc, wm, wn, lane);
-    else mma_steps<Cfg, AR, BR, 4>(Ac, Bc, acc, wm, wn, lane);
+    if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, AR, BR, 1, CS>(Ac, Bc, acc, wm, wn, lane, cs);
+    else mma_steps<Cfg, AR, BR, 4, CS>(Ac, Bc, acc, wm, wn, lane, cs);
 #endif
 #ifdef VQA_DIAG
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -451,9 +459,10 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
 // done(al, bl) runs after the last K-step -- so that MFMA waves spend no VALU on them and, as important,
 // so that their wave-uniform state stays in SGPRs (a value defined under the role test and used after
 // the join would count as divergent).
+// cs != nullptr (uniform): the MFMA waves also accumulate B's column sums (mma_steps CS) into cs[TN].
 template <class Cfg, class AL, class BL, bool SHORT_TAIL = false, class Init, class Done>
 __device__ __forceinline__ bool gemm_mainloop(Init&& init, Done&& done, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0,
-                                              int ks1, int Ktot, float* smem) {
+                                              int ks1, int Ktot, float* smem, float* cs = nullptr) {
   if (is_loader_wave<Cfg>()) {
     AL al; BL bl;
     init(al, bl);
@@ -461,7 +470,8 @@ __device__ __forceinline__ bool gemm_mainloop(Init&& init, Done&& done, f32x16 (
     done(al, bl);
     return false;
   }
-  mfma_loop<Cfg, AL::kTypeR, BL::kTypeR, SHORT_TAIL>(acc, ks0, ks1, Ktot, smem);
+  if (cs) mfma_loop<Cfg, AL::kTypeR, BL::kTypeR, SHORT_TAIL, true>(acc, ks0, ks1, Ktot, smem, cs);
+  else mfma_loop<Cfg, AL::kTypeR, BL::kTypeR, SHORT_TAIL, false>(acc, ks0, ks1, Ktot, smem);
   return true;
 }
 

@@ -130,8 +130,9 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="diagnostic only: dropout off")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostic: take the RCCL data-parallel path even with one rank (under torchrun)")
-    ap.add_argument("--roofline-kernel", default="conv_wgrad:1",
-                    help="kernel family:tag timed live with HIP events (conv_fwd|conv_dgrad|conv_wgrad : layer)")
+    ap.add_argument("--roofline-kernel", default="auto",
+                    help="kernel reported as `roofline`: auto = the kernel family with the most device time; or "
+                         "conv_fwd|conv_dgrad|conv_wgrad[:layer]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,12 +175,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    fam, tag = args.roofline_kernel.split(":")
-    fam_id = {"gemm": 0, "conv_fwd": 1, "conv_dgrad": 2, "conv_wgrad": 3}[fam]
+    FAMS = {0: "gemm", 1: "conv_fwd", 2: "conv_dgrad", 3: "conv_wgrad"}
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    lib.vqa_prof_arm(fam_id, int(tag))
+    lib.vqa_prof_arm(4, -1)                      # VQA_K_COUNT: bracket every kernel family with HIP events
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -189,8 +189,10 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     import ctypes
-    n_launch, tot_ms = ctypes.c_int(0), ctypes.c_float(0.0)
-    lib.vqa_prof_read(ctypes.byref(n_launch), ctypes.byref(tot_ms))
+    cap = 64
+    g_id, g_tag, g_n = (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+    g_ms = (ctypes.c_float * cap)()
+    n_groups = lib.vqa_prof_read_groups(g_id, g_tag, g_n, g_ms, cap)
     lib.vqa_prof_arm(-1, -1)
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev)
@@ -202,25 +204,54 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
         shapes, _ = conv_shapes(S, cfg["image"]["num_channels"], cfg["image"]["stride"])
-        ci, co, Ho, Wo = shapes[int(tag)] if fam != "gemm" else (0, 0, 0, 0)
-        flops_launch = 2.0 * B * Ho * Wo * co * 9 * ci
-        roofline = None
-        if n_launch.value > 0 and flops_launch > 0:
-            avg_ms = tot_ms.value / n_launch.value
-            ach = flops_launch / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": f"{fam}[conv{tag}]", "achieved": round(ach, 2),
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": n_launch.value,
-                        "algorithmic_gflop_per_launch": round(flops_launch / 1e9, 2)}
-        if roofline is not None and B == 256 and S == 224 and int(tag) == 1:
-            # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
-            # rocprofv3 --pmc passes over tools/kbench.py; summary committed under profiles/)
+        # live per-kernel table: every convolution kernel of the step, algorithmic FLOPs / measured launch time
+        traffic_db = {}
+        if B == 256 and S == 224:
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_conv1_traffic.json")) as f:
-                    roofline["traffic"] = int(json.load(f)[fam]["hbm_bytes_corrected"])
-                roofline["traffic_unit"] = "bytes/launch (PMC, profiles/r01_conv1_traffic.json)"
-            except (OSError, KeyError, ValueError):
+                    traffic_db = json.load(f)
+            except (OSError, ValueError):
                 pass
+        kernels = []
+        for g in range(n_groups):
+            fam, tag = FAMS.get(g_id[g]), g_tag[g]
+            if fam in (None, "gemm") or not (0 <= tag < len(shapes)) or g_n[g] == 0:
+                continue
+            ci, co, Ho, Wo = shapes[tag]
+            flops_launch = 2.0 * B * Ho * Wo * co * 9 * ci
+            avg_ms = g_ms[g] / g_n[g]
+            ach = flops_launch / (avg_ms * 1e-3) / 1e12
+            kernels.append({"kernel": f"{fam}[conv{tag}]", "launches": g_n[g], "avg_launch_ms": round(avg_ms, 4),
+                            "algorithmic_gflop_per_launch": round(flops_launch / 1e9, 2),
+                            "achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                            "traffic": (int(traffic_db[f"{fam}:{tag}"]["hbm_bytes_corrected"])
+                                        if f"{fam}:{tag}" in traffic_db else None),
+                            "ms_per_step": round(g_ms[g] / args.steps, 3), "family": fam})
+        # dominant kernel = the kernel NAME with the most device time (rocprofv3 --stats groups by name): the two
+        # forward launches (conv1, conv2) are one kernel, conv_fwd_kernel<T128x128>; --roofline-kernel overrides
+        roofline = None
+        by_fam = {}
+        for k in kernels:
+            by_fam.setdefault(k["family"], []).append(k)
+        pick = args.roofline_kernel
+        if pick == "auto" and by_fam:
+            pick = max(by_fam, key=lambda f: sum(k["ms_per_step"] for k in by_fam[f] if k["kernel"] != f + "[conv0]"))
+        sel = [k for k in kernels if k["family"] == pick.split(":")[0] and k["kernel"] != k["family"] + "[conv0]"
+               and (":" not in pick or k["kernel"].endswith(f"[conv{pick.split(':')[1]}]"))]
+        if sel:
+            n = sum(k["launches"] for k in sel)
+            tot_ms = sum(k["avg_launch_ms"] * k["launches"] for k in sel)
+            gf = sum(k["algorithmic_gflop_per_launch"] * k["launches"] for k in sel)
+            ach = gf / tot_ms                     # GFLOP / ms = TFLOP/s
+            tr = [k["traffic"] for k in sel]
+            roofline = {"bound": "mfma", "kernel": "+".join(k["kernel"] for k in sel), "achieved": round(ach, 2),
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": (int(sum(t * k["launches"] for t, k in zip(tr, sel)) / n) if all(t is not None for t in tr) else None),
+                        "avg_launch_ms": round(tot_ms / n, 4), "launches": n,
+                        "algorithmic_gflop_per_launch": round(gf / n, 2),
+                        "traffic_unit": "bytes/launch (PMC, profiles/r01_conv1_traffic.json)"}
+        for k in kernels:
+            del k["family"]
         gflop_sample = step_flops_per_sample(cfg, S, T) / 1e9
         out = {
             "metric": "VQA samples/sec (train step)", "value": round(value, 2), "unit": "samples/s",
@@ -235,6 +266,7 @@ def main():
             "step_mfma_frac": round(value * gflop_sample / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
             "roofline": roofline,
+            "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, V, A, T)

@@ -21,6 +21,7 @@ PROTOTYPES = {
     "vqa_device_ok": (i32, []),
     "vqa_prof_arm": (i32, [i32, i32]),
     "vqa_prof_read": (i32, [C.POINTER(i32), C.POINTER(f32)]),
+    "vqa_prof_read_groups": (i32, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), i32]),
     "vqa_gemm_workspace_bytes": (i64, [i32, i32, i32]),
     "vqa_gemm": (i32, [f32p, i64, i32, f32p, i64, i32, f32p, i64, i32, i32, i32, f32p, f32p,
                        f32p, i64, i32, i32, i32, i32, f32p, f32p, i64, i32, vp]),

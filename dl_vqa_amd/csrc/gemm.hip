@@ -27,17 +27,19 @@ int check_hip(hipError_t e, const char* what) {
 static std::mutex g_prof_mu;
 static int g_prof_id = -1, g_prof_tag = -1;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
+static std::vector<std::pair<int, int>> g_prof_key;   // (family, tag) of each recorded event pair
 static thread_local int g_launch_tag = -1;
 void set_launch_tag(int tag) { g_launch_tag = tag; }
 
 ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(false) {
   if (g_prof_id < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (g_prof_id != id || (g_prof_tag >= 0 && g_prof_tag != g_launch_tag)) return;
+  if ((g_prof_id != id && g_prof_id != VQA_K_COUNT) || (g_prof_tag >= 0 && g_prof_tag != g_launch_tag)) return;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
   hipEventRecord(a, s);
   g_prof_ev.emplace_back(a, b);
+  g_prof_key.emplace_back(id, g_launch_tag);
   on = true;
 }
 ProfScope::~ProfScope() {
@@ -395,9 +397,27 @@ int vqa_prof_arm(int kernel_id, int tag) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& e : g_prof_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   g_prof_ev.clear();
+  g_prof_key.clear();
   g_prof_id = kernel_id;
   g_prof_tag = tag;
   return VQA_OK;
+}
+
+int vqa_prof_read_groups(int* ids, int* tags, int* launches, float* total_ms, int cap) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = 0;
+  for (size_t e = 0; e < g_prof_ev.size(); ++e) {
+    if (hipEventSynchronize(g_prof_ev[e].second) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof_ev[e].first, g_prof_ev[e].second) != hipSuccess) continue;
+    int g = 0;
+    while (g < n && g < cap && !(ids[g] == g_prof_key[e].first && tags[g] == g_prof_key[e].second)) ++g;
+    if (g >= cap) continue;
+    if (g == n) { ids[g] = g_prof_key[e].first; tags[g] = g_prof_key[e].second; launches[g] = 0; total_ms[g] = 0.f; ++n; }
+    launches[g] += 1;
+    total_ms[g] += ms;
+  }
+  return n;
 }
 
 int vqa_prof_read(int* launches, float* total_ms) {

@@ -48,10 +48,14 @@ enum {
   VQA_K_COUNT = 4
 };
 /* Arm event bracketing for kernel family `kernel_id` whose launch tag equals `tag`
- * (tag < 0: any). kernel_id < 0 disarms. Resets the accumulated numbers. */
+ * (tag < 0: any). kernel_id == VQA_K_COUNT arms every family; kernel_id < 0 disarms.
+ * Resets the accumulated numbers. */
 int vqa_prof_arm(int kernel_id, int tag);
 /* Synchronise the recorded events; returns launches counted and their total device time. */
 int vqa_prof_read(int* launches, float* total_ms);
+/* Per (family, tag) totals of the recorded events: fills up to `cap` entries of ids / tags / launches /
+ * total_ms and returns the number of distinct (family, tag) pairs seen. */
+int vqa_prof_read_groups(int* ids, int* tags, int* launches, float* total_ms, int cap);
 
 /* ---- generic GEMM ---------------------------------------------------------------------------
  * C[M][N] = act( A.B  (op) rowgroup + bias1 + bias2 ) (+ C if accumulate)

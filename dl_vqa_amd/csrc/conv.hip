@@ -154,8 +154,26 @@ static int check_geom(const char* fn, const ConvGeom& g) {
   VQA_REQUIRE((int64_t)g.B * g.H * g.W < (1LL << 31) / 4, "%s: too many pixels for 32-bit row indices", fn);
   // the loaders address each tensor with 32-bit byte offsets from its first element
   VQA_REQUIRE((int64_t)g.B * g.H * g.W * g.CiP * 4 < 0xffff0000LL && (int64_t)g.B * g.Hp * g.Wp * g.Co * 4 < 0xffff0000LL,
-              "%s: a tensor of this layer reaches 4 GiB (B=%d): split the batch", fn, g.B);
+              "%s: a tensor of this launch reaches 4 GiB (B=%d)", fn, g.B);
   return VQA_OK;
+}
+
+// The loaders address every tensor with 32-bit byte offsets, so a launch covers at most `chunk` images (all
+// tensors of the layer below 4 GiB, pixel rows below 2^29); the C ABI entry points walk larger batches in
+// chunks -- images are independent, wgrad's chunks are simply more split-K slabs for the same reduce.
+static int batch_chunk(int B, int H, int W, int CiP, int Co, int stride) {
+  const ConvGeom g = make_geom(1, H, W, CiP, Co, stride);
+  const int64_t in_b = (int64_t)H * W * CiP * 4, out_b = (int64_t)(g.Hp > 0 ? g.Hp : 1) * (g.Wp > 0 ? g.Wp : 1) * Co * 4;
+  const int64_t per_img = in_b > out_b ? in_b : out_b;
+  int64_t c = (0xffff0000LL - 1) / per_img;
+  const int64_t by_rows = ((1LL << 31) / 4 - 1) / ((int64_t)H * W);
+  if (by_rows < c) c = by_rows;
+  if (c > B) c = B;
+  if (const char* e = getenv("VQA_CONV_CHUNK")) {   // tests: force small chunks on small tensors
+    const int64_t f = atoi(e);
+    if (f > 0 && f < c) c = f;
+  }
+  return (int)c;     // 0: a single image is already too large
 }
 
 }  // namespace vqa
@@ -181,14 +199,11 @@ int vqa_conv_pack_weights(const float* w, float* wf, float* wd, int Co, int Ci, 
   return check_hip(hipGetLastError(), "pack_weights launch");
 }
 
-int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* argmax,
-                              int B, int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
-  VQA_REQUIRE(x && wf && bias && pooled && argmax, "vqa_conv3x3_relu_pool_fwd: null pointer");
+static int fwd_chunk(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* argmax, int B, int H,
+                     int W, int CiP, int Co, int stride, vqa_stream_t stream) {
   const ConvGeom g = make_geom(B, H, W, CiP, Co, stride);
   int rc = check_geom("vqa_conv3x3_relu_pool_fwd", g);
   if (rc) return rc;
-  set_launch_tag(tag);
-  ProfScope prof(VQA_K_CONV_FWD, (hipStream_t)stream);
   // Two 128x128 workgroups per CU beat one 256x128 workgroup (8 MFMA + 4 or 8 loader waves) since the loaders
   // left the VALU: conv1 / conv2 forward 84.4 / 88.3 % against 82.7 / 84.7 % (4 loader waves) and 83.6 / 85.2 %
   // (8); on dgrad the gap is wider (72 / 81 % against 56 / 70 % and 66 / 75 %).  The 256-row kernels stay
@@ -203,14 +218,28 @@ int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias
   return launch_fwd<Cfg128x64, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
 }
 
-int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* wd, float* dx, int B, int H, int W,
-                      int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
-  VQA_REQUIRE(dpooled && argmax && wd && dx, "vqa_conv3x3_dgrad: null pointer");
+int vqa_conv3x3_relu_pool_fwd(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* argmax,
+                              int B, int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
+  VQA_REQUIRE(x && wf && bias && pooled && argmax && B > 0, "vqa_conv3x3_relu_pool_fwd: null pointer");
+  const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
+  VQA_REQUIRE(chunk > 0, "vqa_conv3x3_relu_pool_fwd: one %dx%dx%d image reaches 4 GiB", H, W, CiP);
+  const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
+  set_launch_tag(tag);
+  ProfScope prof(VQA_K_CONV_FWD, (hipStream_t)stream);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = B - b0 < chunk ? B - b0 : chunk;
+    const int64_t xo = (int64_t)b0 * H * W * CiP, po = (int64_t)b0 * g1.Hp * g1.Wp * Co;
+    int rc = fwd_chunk(x + xo, wf, bias, pooled + po, argmax + po, nb, H, W, CiP, Co, stride, stream);
+    if (rc) return rc;
+  }
+  return VQA_OK;
+}
+
+static int dgrad_chunk(const float* dpooled, const uint8_t* argmax, const float* wd, float* dx, int B, int H, int W,
+                       int CiP, int Co, int stride, vqa_stream_t stream) {
   const ConvGeom g = make_geom(B, H, W, CiP, Co, stride);
   int rc = check_geom("vqa_conv3x3_dgrad", g);
   if (rc) return rc;
-  set_launch_tag(tag);
-  ProfScope prof(VQA_K_CONV_DGRAD, (hipStream_t)stream);
   const char* bt = getenv("VQA_BIG_TILES");
   const bool many_rows = bt && bt[0] == '1';   // opt-in only, see vqa_conv3x3_relu_pool_fwd
   if (Co % BK != 0) return launch_dgrad<Cfg128x64, false>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
@@ -223,49 +252,84 @@ int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* 
                    : launch_dgrad<Cfg128x64, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
 }
 
+int vqa_conv3x3_dgrad(const float* dpooled, const uint8_t* argmax, const float* wd, float* dx, int B, int H, int W,
+                      int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
+  VQA_REQUIRE(dpooled && argmax && wd && dx && B > 0, "vqa_conv3x3_dgrad: null pointer");
+  const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
+  VQA_REQUIRE(chunk > 0, "vqa_conv3x3_dgrad: one %dx%dx%d image reaches 4 GiB", H, W, CiP);
+  const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
+  set_launch_tag(tag);
+  ProfScope prof(VQA_K_CONV_DGRAD, (hipStream_t)stream);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = B - b0 < chunk ? B - b0 : chunk;
+    const int64_t xo = (int64_t)b0 * H * W * CiP, po = (int64_t)b0 * g1.Hp * g1.Wp * Co;
+    int rc = dgrad_chunk(dpooled + po, argmax + po, wd, dx + xo, nb, H, W, CiP, Co, stride, stream);
+    if (rc) return rc;
+  }
+  return VQA_OK;
+}
+
 int64_t vqa_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride) {
-  const ConvGeom g = make_geom(B, H, W, CiP, Co, stride);
-  if (g.Hp <= 0 || g.Wp <= 0) return 0;
-  const WgradPlan p = plan_wgrad(g);
-  const int64_t slab = (int64_t)p.splits * p.KI * Co * 4;
-  const int64_t bias = (int64_t)p.splits * Co * 4;          // one partial bias row per split
-  return slab + bias;
+  const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
+  if (g1.Hp <= 0 || g1.Wp <= 0 || B <= 0) return 0;
+  const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
+  if (chunk <= 0) return 0;
+  int64_t parts = 0;
+  for (int b0 = 0; b0 < B; b0 += chunk)
+    parts += plan_wgrad(make_geom(B - b0 < chunk ? B - b0 : chunk, H, W, CiP, Co, stride)).splits;
+  // one [9*CiP][Co] slab and one partial bias row per split of every chunk
+  return parts * ((int64_t)9 * CiP * Co + Co) * 4;
 }
 
 int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B,
                       int H, int W, int CiP, int Ci, int Co, int stride, float* workspace, int64_t workspace_bytes,
                       int tag, vqa_stream_t stream) {
-  VQA_REQUIRE(x && dpooled && argmax && dw && dbias && workspace, "vqa_conv3x3_wgrad: null pointer");
-  const ConvGeom g = make_geom(B, H, W, CiP, Co, stride);
-  int rc = check_geom("vqa_conv3x3_wgrad", g);
-  if (rc) return rc;
+  VQA_REQUIRE(x && dpooled && argmax && dw && dbias && workspace && B > 0, "vqa_conv3x3_wgrad: null pointer");
   VQA_REQUIRE(Ci >= 1 && Ci <= CiP, "vqa_conv3x3_wgrad: Ci=%d CiP=%d", Ci, CiP);
-  const WgradPlan p = plan_wgrad(g);
-  const int64_t slab_bytes = (int64_t)p.splits * p.KI * Co * 4;
+  const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
+  VQA_REQUIRE(chunk > 0, "vqa_conv3x3_wgrad: one %dx%dx%d image reaches 4 GiB", H, W, CiP);
   const int64_t need = vqa_conv3x3_wgrad_workspace_bytes(B, H, W, CiP, Co, stride);
   if (workspace_bytes < need) {
     set_error("vqa_conv3x3_wgrad: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
     return VQA_ERR_WORKSPACE;
   }
+  const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
+  const int KI = 9 * CiP;
+  int parts = 0;
+  for (int b0 = 0; b0 < B; b0 += chunk)
+    parts += plan_wgrad(make_geom(B - b0 < chunk ? B - b0 : chunk, H, W, CiP, Co, stride)).splits;
+  float* const bias_slab0 = workspace + (int64_t)parts * KI * Co;
   hipStream_t s = (hipStream_t)stream;
   set_launch_tag(tag);
+  int rc;
   {
     ProfScope prof(VQA_K_CONV_WGRAD, s);
-    float* bias_slab = workspace + slab_bytes / 4;
-    const bool uni = CiP % BK == 0 && Co % BK == 0 && 2 * g.Wp >= BK;
-    rc = p.bm == 96 ? (uni ? launch_wgrad<Cfg96x128, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
-                           : launch_wgrad<Cfg96x128, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
-       : p.big ? (uni ? launch_wgrad<Cfg128W, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
-                      : launch_wgrad<Cfg128W, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s))
-               : (uni ? launch_wgrad<Cfg64, true>(x, dpooled, argmax, workspace, bias_slab, g, p, s)
-                      : launch_wgrad<Cfg64, false>(x, dpooled, argmax, workspace, bias_slab, g, p, s));
-    if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((p.KI * Co + 63) / 64), dim3(256), 0, s, workspace, dw, p.splits,
-                       p.KI, CiP, Ci, Co);
+    int done = 0;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+      const int nb = B - b0 < chunk ? B - b0 : chunk;
+      const ConvGeom g = make_geom(nb, H, W, CiP, Co, stride);
+      rc = check_geom("vqa_conv3x3_wgrad", g);
+      if (rc) return rc;
+      const WgradPlan p = plan_wgrad(g);
+      const float* xc = x + (int64_t)b0 * H * W * CiP;
+      const int64_t po = (int64_t)b0 * g1.Hp * g1.Wp * Co;
+      float* slab = workspace + (int64_t)done * KI * Co;
+      float* bias_slab = bias_slab0 + (int64_t)done * Co;
+      const bool uni = CiP % BK == 0 && Co % BK == 0 && 2 * g.Wp >= BK;
+      rc = p.bm == 96 ? (uni ? launch_wgrad<Cfg96x128, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
+                             : launch_wgrad<Cfg96x128, false>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s))
+         : p.big ? (uni ? launch_wgrad<Cfg128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
+                        : launch_wgrad<Cfg128W, false>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s))
+                 : (uni ? launch_wgrad<Cfg64, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
+                        : launch_wgrad<Cfg64, false>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s));
+      if (rc) return rc;
+      done += p.splits;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((KI * Co + 63) / 64), dim3(256), 0, s, workspace, dw, parts, KI, CiP,
+                       Ci, Co);
     rc = check_hip(hipGetLastError(), "wgrad_reduce launch");
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bias_slab, dbias,
-                       p.splits, Co);
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bias_slab0, dbias, parts, Co);
     rc = check_hip(hipGetLastError(), "wgrad_bias_reduce launch");
   }
   return rc;

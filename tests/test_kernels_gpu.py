@@ -466,6 +466,35 @@ def test_conv0_dedicated_fwd_wgrad(B, Ci, H, W, Co):
 
 
 # ----------------------------------------------------------------------------- every tile configuration
+def test_conv_batch_chunking(monkeypatch):
+    """Batches whose tensors would pass 4 GiB are walked in chunks inside the C ABI (32-bit offsets per launch);
+    VQA_CONV_CHUNK forces that path on small tensors: forward and dgrad are bit-identical to one launch, wgrad's
+    chunks are extra split-K slabs of the same reduce."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    B, H, Ci, Co = 5, 26, 32, 64
+    x = torch.randn(B, H, H, Ci, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).to(DEV)
+    b = (torch.randn(Co, generator=g) * 0.1).to(DEV)
+    wf, wd = ops.conv_pack_weights(w, Ci)
+
+    def run():
+        pooled, am = ops.conv_fwd(x, wf, b, 1)
+        dp = torch.sin(pooled * 3.0) + 0.1
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        ops.conv_wgrad(x, dp, am, dw, db, 1)
+        dx = ops.conv_dgrad(dp, am, wd, x.shape, 1)
+        torch.cuda.synchronize()
+        return pooled, am, dw, db, dx
+
+    ref = run()
+    monkeypatch.setenv("VQA_CONV_CHUNK", "2")      # 2 + 2 + 1 images
+    got = run()
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and torch.equal(ref[4], got[4])
+    check("chunked wgrad dw", got[2], ref[2].double(), 1e-5)
+    check("chunked wgrad db", got[3], ref[3].double(), 1e-5)
+
+
 @pytest.mark.parametrize("persistent", ["0", "1"])
 def test_persistent_tiles_forced(persistent, monkeypatch):
     """VQA_PERSISTENT forces the persistent-tile kernels (normally chosen for short-K GEMMs only) on or off."""

@@ -39,6 +39,13 @@ using Cfg96x128 = TileCfg<96, 128, 1, 4, 4, VQA_WGRAD_PF>;
 // wgrad streams new pixels from HBM every K-step: three K-steps of loads in flight (75 -> 78 % on conv1 in spite
 // of ~55 spilled loader registers; four spill 100+ and lose 15 points; dgrad's 128x64 tile loses 9 points at three)
 using Cfg128W = TileCfg<128, 128, 2, 2, 4, VQA_WGRAD_PF>;
+#ifndef VQA_W192_PF
+#define VQA_W192_PF 3
+#endif
+// opt-in (VQA_WGRAD_192=1): 192 rows, 8 MFMA waves (2 x 4, 96x32 each) + 4 loader waves, one workgroup per CU (84 KB
+// LDS, 164 VGPRs): the routed B operand is reloaded by 3 (conv1) / 6 (conv2) row tiles instead of 6 / 9, but one
+// workgroup per CU costs more than that saves: conv1 76.0 -> 77.1 %, conv2 82.5 -> 75.7 % (same box)
+using Cfg192x128W = TileCfg<192, 128, 2, 4, 4, VQA_W192_PF>;
 // the same tiles with 8 loader waves (1024 threads): two loader waves per SIMD for loader-bound K loops
 using Cfg256x128L8 = TileCfg<256, 128, 4, 2, 8>;
 using Cfg256x64L8 = TileCfg<256, 64, 4, 2, 8>;
@@ -118,13 +125,14 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
   const int bn = p.big ? 128 : 64;
   // 96-row tiles when they waste fewer rows than 128-row tiles (KI = 576: 576 vs 640 rows of MFMA work)
   p.bm = !p.big ? 64 : ((p.KI + 95) / 96 * 96 < (p.KI + 127) / 128 * 128 ? 96 : 128);
+  if (p.big && p.KI % 192 == 0 && g.CiP % BK == 0 && g.Co % BK == 0 && 2 * g.Wp >= BK && getenv("VQA_WGRAD_192")) p.bm = 192;
   p.tiles_m = (p.KI + p.bm - 1) / p.bm;
   p.tiles_n = (g.Co + bn - 1) / bn;
   p.nk = (p.Mtot + BK - 1) / BK;
   const int tiles = p.tiles_m * p.tiles_n;
   // 2 workgroups fit a CU (LDS): tiles * splits must not exceed the 512 resident slots, or the few
   // workgroups left over run alone in a second round and double the kernel's time.
-  int splits = 512 / tiles;
+  int splits = (p.bm == 192 ? 256 : 512) / tiles;
   if (splits < 1) splits = 1;
   const int max_splits = p.nk / 8 > 1 ? p.nk / 8 : 1;
   if (splits > max_splits) splits = max_splits;
@@ -320,7 +328,8 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
       float* slab = workspace + (int64_t)done * KI * Co;
       float* bias_slab = bias_slab0 + (int64_t)done * Co;
       const bool uni = CiP % BK == 0 && Co % BK == 0 && 2 * g.Wp >= BK;
-      rc = p.bm == 96 ? (uni ? launch_wgrad<Cfg96x128, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
+      rc = p.bm == 192 ? launch_wgrad<Cfg192x128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
+         : p.bm == 96 ? (uni ? launch_wgrad<Cfg96x128, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
                              : launch_wgrad<Cfg96x128, false>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s))
          : p.big ? (uni ? launch_wgrad<Cfg128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
                         : launch_wgrad<Cfg128W, false>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s))

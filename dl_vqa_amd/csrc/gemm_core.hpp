@@ -40,6 +40,9 @@ static __device__ unsigned long long vqa_diag_ld[4];
 #ifndef VQA_PRIO_MFMA
 #define VQA_PRIO_MFMA 3
 #endif
+#ifndef VQA_EARLY_BARRIER
+#define VQA_EARLY_BARRIER 1   // K-step barrier in front of the last fragment group (mfma_loop_eb)
+#endif
 #ifndef VQA_PF128
 #define VQA_PF128 2   // K-steps of loads in flight for tiles up to 128x128
 #endif
@@ -453,6 +456,80 @@ __device__ __forceinline__ void mfma_loop(f32x16 (&acc)[Cfg::TM][Cfg::TN], int k
 #endif
 }
 
+// MFMA role with the K-step barrier moved in front of the LAST fragment group.  By then every fragment of the
+// stage is in registers (group 3 was fetched under group 2's MFMAs), so the stage can be handed back to the
+// loaders a quarter of a K-step early, and the first fragments of the NEXT stage are fetched under group 3's
+// MFMAs instead of after the barrier with the MFMA pipe idle.  Same number of barriers as mfma_loop.
+template <class Cfg, bool AR, bool BR, bool CS>
+__device__ __forceinline__ void mfma_loop_eb(f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1, const float* smem,
+                                             float* cs) {
+  using SL = SmemLayout<Cfg, AR, BR>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const int l31 = lane & 31, h = lane >> 5;
+  constexpr int CSA = LdsImage<Cfg::BM>::CS, CSB = LdsImage<Cfg::BN>::CS;
+  const float* const As0 = smem + (AR ? (wm * Cfg::WM + l31) * LDS_RS + 4 * h : 4 * h * CSA + wm * Cfg::WM + l31);
+  const float* const Bs0 = smem + 2 * SL::ABUF + (BR ? (wn * Cfg::WN + l31) * LDS_RS + 4 * h : 4 * h * CSB + wn * Cfg::WN + l31);
+  float a[2][4][Cfg::TM], b[2][4][Cfg::TN];
+  auto fetch = [&](const float* ap, const float* bp, int t, int buf) {
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      if (AR) {
+        const float4 v = *reinterpret_cast<const float4*>(ap + 32 * i * LDS_RS + 8 * t);
+        a[buf][0][i] = v.x; a[buf][1][i] = v.y; a[buf][2][i] = v.z; a[buf][3][i] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[buf][q][i] = ap[(8 * t + q) * CSA + 32 * i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      if (BR) {
+        const float4 v = *reinterpret_cast<const float4*>(bp + 32 * j * LDS_RS + 8 * t);
+        b[buf][0][j] = v.x; b[buf][1][j] = v.y; b[buf][2][j] = v.z; b[buf][3][j] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[buf][q][j] = bp[(8 * t + q) * CSB + 32 * j];
+      }
+    }
+  };
+  auto mma = [&](int buf) {
+    if (CS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) cs[j] += b[buf][q][j];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][q][i], b[buf][q][j], acc[i][j], 0, 0, 0);
+  };
+  __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
+  __syncthreads();
+  fetch(As0, Bs0, 0, 0);
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int cur = (ks - ks0) & 1;
+    const float* const Ac = As0 + cur * SL::ABUF;
+    const float* const Bc = Bs0 + cur * SL::BBUF;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      fetch(Ac, Bc, t + 1, (t + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);   // reads of group t+1 stay above the MFMAs of group t
+      mma(t & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // every fragment of this stage is in registers; the next stage is complete
+    if (ks + 1 < ks1) fetch(As0 + (cur ^ 1) * SL::ABUF, Bs0 + (cur ^ 1) * SL::BBUF, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);            // group 3, under the next stage's first fragment reads
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Whole contraction over K-steps [ks0, ks1) (ks1 > ks0).  Returns true for MFMA waves (which hold the
 // accumulators and run the epilogue); loader waves return false and must do nothing further that
 // needs a barrier.  The loaders live entirely inside the loader branch -- init(al, bl) sets them up,
@@ -470,6 +547,13 @@ __device__ __forceinline__ bool gemm_mainloop(Init&& init, Done&& done, f32x16 (
     done(al, bl);
     return false;
   }
+#if VQA_EARLY_BARRIER && !defined(VQA_DIAG) && !defined(VQA_EXP_SKIP_MFMA)
+  if (!SHORT_TAIL) {
+    if (cs) mfma_loop_eb<Cfg, AL::kTypeR, BL::kTypeR, true>(acc, ks0, ks1, smem, cs);
+    else mfma_loop_eb<Cfg, AL::kTypeR, BL::kTypeR, false>(acc, ks0, ks1, smem, nullptr);
+    return true;
+  }
+#endif
   if (cs) mfma_loop<Cfg, AL::kTypeR, BL::kTypeR, SHORT_TAIL, true>(acc, ks0, ks1, Ktot, smem, cs);
   else mfma_loop<Cfg, AL::kTypeR, BL::kTypeR, SHORT_TAIL, false>(acc, ks0, ks1, Ktot, smem);
   return true;

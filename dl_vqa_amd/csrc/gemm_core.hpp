@@ -41,7 +41,7 @@ static __device__ unsigned long long vqa_diag_ld[4];
 #define VQA_PRIO_MFMA 3
 #endif
 #ifndef VQA_EARLY_BARRIER
-#define VQA_EARLY_BARRIER 1   // K-step barrier in front of the last fragment group (mfma_loop_eb)
+#define VQA_EARLY_BARRIER 2   // K-step barrier in front of the last fragment group (2: last two for 64x64 tiles)
 #endif
 #ifndef VQA_PF128
 #define VQA_PF128 2   // K-steps of loads in flight for tiles up to 128x128
@@ -470,7 +470,10 @@ __device__ __forceinline__ void mfma_loop_eb(f32x16 (&acc)[Cfg::TM][Cfg::TN], in
   constexpr int CSA = LdsImage<Cfg::BM>::CS, CSB = LdsImage<Cfg::BN>::CS;
   const float* const As0 = smem + (AR ? (wm * Cfg::WM + l31) * LDS_RS + 4 * h : 4 * h * CSA + wm * Cfg::WM + l31);
   const float* const Bs0 = smem + 2 * SL::ABUF + (BR ? (wn * Cfg::WN + l31) * LDS_RS + 4 * h : 4 * h * CSB + wn * Cfg::WN + l31);
-  float a[2][4][Cfg::TM], b[2][4][Cfg::TN];
+  // 64x64 tiles (one MFMA tile per wave, 16 MFMAs per K-step) put the barrier in front of the last TWO groups:
+  // four fragment buffers of 8 registers, the stage goes back to the loaders half a K-step early
+  constexpr bool EB2 = Cfg::TM * Cfg::TN == 1 && VQA_EARLY_BARRIER >= 2;
+  float a[EB2 ? 4 : 2][4][Cfg::TM], b[EB2 ? 4 : 2][4][Cfg::TN];
   auto fetch = [&](const float* ap, const float* bp, int t, int buf) {
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i) {
@@ -510,6 +513,36 @@ __device__ __forceinline__ void mfma_loop_eb(f32x16 (&acc)[Cfg::TM][Cfg::TN], in
   };
   __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
   __syncthreads();
+  if (EB2) {
+    // buffers 0,1 hold groups 0,1 of the current stage on entry to a K-step; 2,3 take groups 2,3
+    fetch(As0, Bs0, 0, 0);
+    fetch(As0, Bs0, 1, 1);
+    for (int ks = ks0; ks < ks1; ++ks) {
+      const int cur = (ks - ks0) & 1;
+      const float* const Ac = As0 + cur * SL::ABUF;
+      const float* const Bc = Bs0 + cur * SL::BBUF;
+      const float* const An = As0 + (cur ^ 1) * SL::ABUF;
+      const float* const Bn = Bs0 + (cur ^ 1) * SL::BBUF;
+      fetch(Ac, Bc, 2, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(Ac, Bc, 3, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();   // groups 2, 3 are in registers: the stage is free; the next stage is complete
+      if (ks + 1 < ks1) fetch(An, Bn, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < ks1) fetch(An, Bn, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   fetch(As0, Bs0, 0, 0);
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;

@@ -472,7 +472,7 @@ __device__ __forceinline__ void mfma_loop_eb(f32x16 (&acc)[Cfg::TM][Cfg::TN], in
   const float* const Bs0 = smem + 2 * SL::ABUF + (BR ? (wn * Cfg::WN + l31) * LDS_RS + 4 * h : 4 * h * CSB + wn * Cfg::WN + l31);
   // 64x64 tiles (one MFMA tile per wave, 16 MFMAs per K-step) put the barrier in front of the last TWO groups:
   // four fragment buffers of 8 registers, the stage goes back to the loaders half a K-step early
-  constexpr bool EB2 = Cfg::TM * Cfg::TN == 1 && VQA_EARLY_BARRIER >= 2;
+  constexpr bool EB2 = Cfg::TM * Cfg::TN == 1 && VQA_EARLY_BARRIER >= 2;   // (no gain on the 96x128 wgrad tile)
   float a[EB2 ? 4 : 2][4][Cfg::TM], b[EB2 ? 4 : 2][4][Cfg::TN];
   auto fetch = [&](const float* ap, const float* bp, int t, int buf) {
 #pragma unroll

@@ -238,34 +238,43 @@ __global__ void splitk_reduce_kernel(EpiParams pe, int splits) {
   }
 }
 
-// N % 4 == 0: a thread owns 4 consecutive columns, the slab reads are 16-byte loads issued four splits at a
-// time (the scalar version above is a chain of dependent 4-byte loads: 16 us for an 8-split 256 x 1024 output).
-// The summation order over the splits is the same as in the scalar kernel.
+// N % 4 == 0: 16-byte slab reads; a block covers 64 float4 outputs with 4 thread groups that each take every 4th
+// split, so all the loads of a thread are in flight at once (the scalar kernel above is a chain of dependent
+// 4-byte loads: 16 us for an 8-split 256 x 1024 output), and the groups combine through LDS in a fixed order.
 __global__ __launch_bounds__(256) void splitk_reduce4_kernel(EpiParams pe, int splits) {
+  __shared__ float4 part[4][64];
   const int64_t total4 = (int64_t)pe.M * pe.N / 4;
   const int n4 = pe.N / 4;
   const float4* slab = reinterpret_cast<const float4*>(pe.slab);
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4;
-       e += (int64_t)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total4; e0 += (int64_t)gridDim.x * 64) {
+    const int64_t e = e0 + lane;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 4 <= splits; s += 4) {
-      const float4 a = slab[(int64_t)s * total4 + e], b = slab[(int64_t)(s + 1) * total4 + e];
-      const float4 c = slab[(int64_t)(s + 2) * total4 + e], d = slab[(int64_t)(s + 3) * total4 + e];
-      v.x = (((v.x + a.x) + b.x) + c.x) + d.x; v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
-      v.z = (((v.z + a.z) + b.z) + c.z) + d.z; v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+    if (e < total4) {
+      int s = grp;
+      for (; s + 4 < splits; s += 8) {          // two independent loads per trip
+        const float4 a = slab[(int64_t)s * total4 + e], b = slab[(int64_t)(s + 4) * total4 + e];
+        v.x = (v.x + a.x) + b.x; v.y = (v.y + a.y) + b.y; v.z = (v.z + a.z) + b.z; v.w = (v.w + a.w) + b.w;
+      }
+      if (s < splits) {
+        const float4 a = slab[(int64_t)s * total4 + e];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
     }
-    for (; s < splits; ++s) {
-      const float4 a = slab[(int64_t)s * total4 + e];
-      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    }
-    const int row = (int)(e / n4), col = 4 * (int)(e - (int64_t)row * n4);
-    const float r[4] = {v.x, v.y, v.z, v.w};
+    part[grp][lane] = v;
+    __syncthreads();
+    if (grp == 0 && e < total4) {
+      const float4 p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+      const float r[4] = {(v.x + p1.x) + (p2.x + p3.x), (v.y + p1.y) + (p2.y + p3.y),
+                          (v.z + p1.z) + (p2.z + p3.z), (v.w + p1.w) + (p2.w + p3.w)};
+      const int row = (int)(e / n4), col = 4 * (int)(e - (int64_t)row * n4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (pe.aux) pe.aux[(int64_t)row * pe.ldc + col + k] = r[k];
-      pe.C[(int64_t)row * pe.ldc + col + k] = epi_apply(pe, r[k], row, col + k);
+      for (int k = 0; k < 4; ++k) {
+        if (pe.aux) pe.aux[(int64_t)row * pe.ldc + col + k] = r[k];
+        pe.C[(int64_t)row * pe.ldc + col + k] = epi_apply(pe, r[k], row, col + k);
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -474,7 +483,7 @@ int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ld
     if (p.splits > 1) {
       const bool vec = N % 4 == 0;
       const int64_t total = (int64_t)M * N / (vec ? 4 : 1);
-      int blocks = (int)((total + 255) / 256);
+      int blocks = (int)((total + (vec ? 63 : 255)) / (vec ? 64 : 256));
       if (blocks > 4096) blocks = 4096;
       if (vec) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks), dim3(256), 0, s, pe, p.splits);
       else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, pe, p.splits);

@@ -42,9 +42,8 @@ using Cfg128W = TileCfg<128, 128, 2, 2, 4, VQA_WGRAD_PF>;
 #ifndef VQA_W192_PF
 #define VQA_W192_PF 3
 #endif
-// opt-in (VQA_WGRAD_192=1): 192 rows, 8 MFMA waves (2 x 4, 96x32 each) + 4 loader waves, one workgroup per CU (84 KB
-// LDS, 164 VGPRs): the routed B operand is reloaded by 3 (conv1) / 6 (conv2) row tiles instead of 6 / 9, but one
-// workgroup per CU costs more than that saves: conv1 76.0 -> 77.1 %, conv2 82.5 -> 75.7 % (same box)
+// 192 rows, 8 MFMA waves (2 x 4, 96x32 each) + 4 loader waves, one workgroup per CU (84 KB LDS, 164 VGPRs): the routed
+// B operand is reloaded by 3 (conv1) / 6 (conv2) row tiles instead of 6 / 9 (see plan_wgrad for when it is used)
 using Cfg192x128W = TileCfg<192, 128, 2, 4, 4, VQA_W192_PF>;
 // the same tiles with 8 loader waves (1024 threads): two loader waves per SIMD for loader-bound K loops
 using Cfg256x128L8 = TileCfg<256, 128, 4, 2, 8>;
@@ -125,7 +124,15 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
   const int bn = p.big ? 128 : 64;
   // 96-row tiles when they waste fewer rows than 128-row tiles (KI = 576: 576 vs 640 rows of MFMA work)
   p.bm = !p.big ? 64 : ((p.KI + 95) / 96 * 96 < (p.KI + 127) / 128 * 128 ? 96 : 128);
-  if (p.big && p.KI % 192 == 0 && g.CiP % BK == 0 && g.Co % BK == 0 && 2 * g.Wp >= BK && getenv("VQA_WGRAD_192")) p.bm = 192;
+  // 9*CiP = 576 (CiP = 64): three 192-row tiles (8 MFMA waves, one workgroup per CU) instead of six 96-row tiles halve
+  // the reloads of the routed B operand: 76.6 -> 80.3 % with the early K-step barrier (before it: +1 point); where
+  // 128-row tiles fit exactly (9*CiP = 1152) two 128x128 workgroups per CU stay ahead (83.0 vs 79.4 %).
+  // VQA_WGRAD_192=0 / 1 disables / forces it wherever 9*CiP % 192 == 0.
+  {
+    const char* w192 = getenv("VQA_WGRAD_192");
+    const bool can = p.big && p.KI % 192 == 0 && g.CiP % BK == 0 && g.Co % BK == 0 && 2 * g.Wp >= BK;
+    if (can && (w192 ? w192[0] == '1' : p.bm == 96)) p.bm = 192;
+  }
   p.tiles_m = (p.KI + p.bm - 1) / p.bm;
   p.tiles_n = (g.Co + bn - 1) / bn;
   p.nk = (p.Mtot + BK - 1) / BK;

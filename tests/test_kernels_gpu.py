@@ -495,9 +495,11 @@ def test_conv_batch_chunking(monkeypatch):
     check("chunked wgrad db", got[3], ref[3].double(), 1e-5)
 
 
-def test_wgrad_192_row_tiles_forced(monkeypatch):
-    """The opt-in 192x128 wgrad tile (8 MFMA waves, one workgroup per CU) is parity-checked like the default ones."""
-    monkeypatch.setenv("VQA_WGRAD_192", "1")
+@pytest.mark.parametrize("force", ["0", "1"])
+def test_wgrad_192_row_tiles_forced(force, monkeypatch):
+    """The 192x128 wgrad tile (8 MFMA waves, one workgroup per CU; default where 9*CiP = 576) and the 96- / 128-row
+    tiles it replaces are all parity-checked: VQA_WGRAD_192 forces either choice."""
+    monkeypatch.setenv("VQA_WGRAD_192", force)
     test_conv_relu_pool_fwd_bwd(2, 58, 58, 64, 128, 1)
     test_conv_relu_pool_fwd_bwd(1, 30, 30, 128, 256, 1)
 

@@ -28,8 +28,11 @@ using Cfg128 = TileCfg<128, 128, 2, 2>;
 using Cfg128x64 = TileCfg<128, 64, 2, 2>;
 // 256-row tiles for the pixel-major GEMMs (forward / dgrad: M = millions of pixels): 25 % fewer bytes
 // staged per MFMA than 128x128 (tools/mfma_ws.hip: 83 % -> 88 % of the MFMA rate in the same skeleton).
-using Cfg256x128 = TileCfg<256, 128, 4, 2>;   // 8 MFMA waves (64x64 each) + 4 loader waves, one workgroup per CU
-using Cfg256x64 = TileCfg<256, 64, 4, 2>;     // 8 MFMA waves (64x32 each)
+#ifndef VQA_BIG_PF
+#define VQA_BIG_PF 0
+#endif
+using Cfg256x128 = TileCfg<256, 128, 4, 2, 4, VQA_BIG_PF>;   // 8 MFMA waves (64x64 each) + 4 loader waves, one workgroup per CU
+using Cfg256x64 = TileCfg<256, 64, 4, 2, 4, VQA_BIG_PF>;     // 8 MFMA waves (64x32 each)
 using Cfg64 = TileCfg<64, 64, 2, 2>;
 // wgrad rows are (tap, ci): 9*CiP = 576 for CiP = 64 is 4.5 x 128 but 6 x 96 (1 x 4 MFMA waves of 96x32)
 #ifndef VQA_WGRAD_PF

@@ -48,6 +48,7 @@ using Cfg128W = TileCfg<128, 128, 2, 2, 4, VQA_WGRAD_PF>;
 // 192 rows, 8 MFMA waves (2 x 4, 96x32 each) + 4 loader waves, one workgroup per CU (84 KB LDS, 164 VGPRs): the routed
 // B operand is reloaded by 3 (conv1) / 6 (conv2) row tiles instead of 6 / 9 (see plan_wgrad for when it is used)
 using Cfg192x128W = TileCfg<192, 128, 2, 4, 4, VQA_W192_PF>;
+using Cfg384x128W = TileCfg<384, 128, 4, 2, 4, 2>;   // 9*CiP = 1152 as three row tiles (see plan_wgrad)
 // the same tiles with 8 loader waves (1024 threads): two loader waves per SIMD for loader-bound K loops
 using Cfg256x128L8 = TileCfg<256, 128, 4, 2, 8>;
 using Cfg256x64L8 = TileCfg<256, 64, 4, 2, 8>;
@@ -135,6 +136,10 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
     const char* w192 = getenv("VQA_WGRAD_192");
     const bool can = p.big && p.KI % 192 == 0 && g.CiP % BK == 0 && g.Co % BK == 0 && 2 * g.Wp >= BK;
     if (can && (w192 ? w192[0] == '1' : p.bm == 96)) p.bm = 192;
+    // 9*CiP = 1152 (CiP = 128): three 384-row tiles (8 MFMA waves of 96x64, one workgroup per CU, 133 KB LDS) reload
+    // the routed B operand 3x instead of 9x: 82.4 -> 86.6 % (same box).  VQA_WGRAD_384=0 / 1 disables / forces it.
+    const char* w384 = getenv("VQA_WGRAD_384");
+    if (can && p.KI % 384 == 0 && !(w192 && w192[0] == '1') && (w384 ? w384[0] == '1' : true)) p.bm = 384;
   }
   p.tiles_m = (p.KI + p.bm - 1) / p.bm;
   p.tiles_n = (g.Co + bn - 1) / bn;
@@ -142,7 +147,7 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
   const int tiles = p.tiles_m * p.tiles_n;
   // 2 workgroups fit a CU (LDS): tiles * splits must not exceed the 512 resident slots, or the few
   // workgroups left over run alone in a second round and double the kernel's time.
-  int splits = (p.bm == 192 ? 256 : 512) / tiles;
+  int splits = (p.bm >= 192 ? 256 : 512) / tiles;
   if (splits < 1) splits = 1;
   const int max_splits = p.nk / 8 > 1 ? p.nk / 8 : 1;
   if (splits > max_splits) splits = max_splits;
@@ -338,7 +343,8 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
       float* slab = workspace + (int64_t)done * KI * Co;
       float* bias_slab = bias_slab0 + (int64_t)done * Co;
       const bool uni = CiP % BK == 0 && Co % BK == 0 && 2 * g.Wp >= BK;
-      rc = p.bm == 192 ? launch_wgrad<Cfg192x128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
+      rc = p.bm == 384 ? launch_wgrad<Cfg384x128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
+         : p.bm == 192 ? launch_wgrad<Cfg192x128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
          : p.bm == 96 ? (uni ? launch_wgrad<Cfg96x128, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
                              : launch_wgrad<Cfg96x128, false>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s))
          : p.big ? (uni ? launch_wgrad<Cfg128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)

@@ -495,11 +495,12 @@ def test_conv_batch_chunking(monkeypatch):
     check("chunked wgrad db", got[3], ref[3].double(), 1e-5)
 
 
-@pytest.mark.parametrize("force", ["0", "1"])
-def test_wgrad_192_row_tiles_forced(force, monkeypatch):
-    """The 192x128 wgrad tile (8 MFMA waves, one workgroup per CU; default where 9*CiP = 576) and the 96- / 128-row
-    tiles it replaces are all parity-checked: VQA_WGRAD_192 forces either choice."""
-    monkeypatch.setenv("VQA_WGRAD_192", force)
+@pytest.mark.parametrize("w192,w384", [("0", "0"), ("1", "0"), ("0", "1")])
+def test_wgrad_tall_tiles_forced(w192, w384, monkeypatch):
+    """The tall wgrad tiles (192x128 where 9*CiP = 576, 384x128 where 9*CiP = 1152: 8 MFMA waves, one workgroup
+    per CU) and the 96- / 128-row tiles they replace are all parity-checked: the two variables force every choice."""
+    monkeypatch.setenv("VQA_WGRAD_192", w192)
+    monkeypatch.setenv("VQA_WGRAD_384", w384)
     test_conv_relu_pool_fwd_bwd(2, 58, 58, 64, 128, 1)
     test_conv_relu_pool_fwd_bwd(1, 30, 30, 128, 256, 1)
 

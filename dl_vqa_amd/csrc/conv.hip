@@ -343,6 +343,7 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
       float* slab = workspace + (int64_t)done * KI * Co;
       float* bias_slab = bias_slab0 + (int64_t)done * Co;
       const bool uni = CiP % BK == 0 && Co % BK == 0 && 2 * g.Wp >= BK;
+      // (8 loader waves on the 192-row tile: +0.5 %, with 3 or 4 K-steps in flight alike; not worth the kernels)
       rc = p.bm == 384 ? launch_wgrad<Cfg384x128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
          : p.bm == 192 ? launch_wgrad<Cfg192x128W, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)
          : p.bm == 96 ? (uni ? launch_wgrad<Cfg96x128, true>(xc, dpooled + po, argmax + po, slab, bias_slab, g, p, s)

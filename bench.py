@@ -227,8 +227,10 @@ def main():
                             "traffic": (int(traffic_db[f"{fam}:{tag}"]["hbm_bytes_corrected"])
                                         if f"{fam}:{tag}" in traffic_db else None),
                             "ms_per_step": round(g_ms[g] / args.steps, 3), "family": fam})
-        # dominant kernel = the kernel NAME with the most device time (rocprofv3 --stats groups by name): the two
-        # forward launches (conv1, conv2) are one kernel, conv_fwd_kernel<T128x128>; --roofline-kernel overrides
+        # dominant kernel = the kernel FAMILY (conv_fwd / conv_dgrad / conv_wgrad, conv1 + conv2 launches together)
+        # with the most device time in the step; --roofline-kernel conv_fwd|conv_dgrad|conv_wgrad[:layer] overrides.
+        # (rocprofv3 --stats groups by kernel NAME instead, where the two forward launches share one name and rank
+        # first; the family choice is the more conservative fraction.)
         roofline = None
         by_fam = {}
         for k in kernels:

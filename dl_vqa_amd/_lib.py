@@ -19,6 +19,7 @@ PROTOTYPES = {
     "vqa_abi_version": (i32, []),
     "vqa_last_error": (C.c_char_p, []),
     "vqa_device_ok": (i32, []),
+    "vqa_reload_knobs": (i32, []),
     "vqa_prof_arm": (i32, [i32, i32]),
     "vqa_prof_read": (i32, [C.POINTER(i32), C.POINTER(f32)]),
     "vqa_prof_read_groups": (i32, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), i32]),
@@ -39,7 +40,7 @@ PROTOTYPES = {
     "vqa_dropout": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp]),
     "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, f32, u64, vp]),
-    "vqa_embed_tanh_fwd": (i32, [i64p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
+    "vqa_embed_tanh_fwd": (i32, [i64p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp, vp]),
     "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
     "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
     "vqa_lstm_cell_bwd": (i32, [f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, i32, i32, vp]),

@@ -21,6 +21,24 @@ int check_hip(hipError_t e, const char* what);
     }                                          \
   } while (0)
 
+// ---------------------------------------------------------------- launch plumbing
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for a kernel, once per (device, kernel); thread-safe.
+int ensure_dyn_smem(const void* kernel, int bytes, const char* what);
+
+// VQA_* environment knobs (diagnostics / forced tile variants for the parity tests).  Read ONCE, when the
+// library is first used; vqa_reload_knobs() re-reads them (tests that switch variants inside one process).
+//   -1 = unset (the planner decides)
+struct Knobs {
+  int split_target;       // VQA_SPLIT_TARGET: resident-workgroup target of the split-K planner (default 512)
+  int big_tiles;          // VQA_BIG_TILES 0/1/2/3
+  int persistent;         // VQA_PERSISTENT 0/1
+  int weight_stationary;  // VQA_WEIGHT_STATIONARY 0/1
+  int wgrad_192;          // VQA_WGRAD_192 0/1
+  int wgrad_384;          // VQA_WGRAD_384 0/1
+  int conv_chunk;         // VQA_CONV_CHUNK: images per conv launch (tests)
+};
+const Knobs& knobs();
+
 // ---------------------------------------------------------------- profiling hook
 // When a kernel id is armed (vqa_prof_arm), every launch of that kernel is bracketed by HIP
 // events recorded on the launch stream; vqa_prof_read() returns count and total milliseconds.

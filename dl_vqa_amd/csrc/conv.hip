@@ -14,7 +14,6 @@
 // wgrad     out[(ky,kx,ci)][co] = sum over conv-output pixels; split along that (huge) reduction over
 //           workgroups into slabs, then reduced and transposed to the torch layout [Co][Ci][3][3].
 #include "gemm_core.hpp"
-#include "gemm_core.hpp"
 
 namespace vqa {
 
@@ -58,8 +57,7 @@ using Cfg128x64L8 = TileCfg<128, 64, 2, 2, 8, 2>;
 
 template <class K>
 static int set_smem(K kern, int bytes, const char* what) {
-  return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
+  return ensure_dyn_smem(reinterpret_cast<const void*>(kern), bytes, what);
 }
 
 template <class Cfg, bool U>
@@ -71,22 +69,19 @@ static int launch_fwd(const float* x, const float* wf, const float* bias, float*
   typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wf, g.Co, g.Co, K};
   const int tiles_m = (4 * nWin + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.Co + Cfg::BN - 1) / Cfg::BN;
   const int slots = 256 * SL::WG_PER_CU, tiles = tiles_m * tiles_n;
-  const char* pt = getenv("VQA_PERSISTENT");
   // Persistent tiles measured neutral to slower on the conv kernels (conv1 fwd 3.83 -> 3.81 ms, conv2 dgrad
   // 3.65 -> 3.93 ms: their K loops are long and the second workgroup / MFMA wave of the SIMD already covers a
   // tile's prologue and epilogue), so they are opt-in (VQA_PERSISTENT=1) and parity-tested that way.
-  const bool persistent = pt && pt[0] == '1';
+  const bool persistent = knobs().persistent == 1;
   if (persistent) {
     auto pk = conv_fwd_persistent_kernel<Cfg, U>;
-    static bool done2 = false;
-    if (!done2) { int rc = set_smem(pk, SL::BYTES, "attr(conv_fwd_p)"); if (rc) return rc; done2 = true; }
+    { int rc = set_smem(pk, SL::BYTES, "attr(conv_fwd_p)"); if (rc) return rc; }
     hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, bias,
                        pooled, amax, g.Co, tiles_m, tiles_n, (K + BK - 1) / BK);
     return check_hip(hipGetLastError(), "conv_fwd_persistent launch");
   }
   auto kern = conv_fwd_kernel<Cfg, U>;
-  static bool done = false;
-  if (!done) { int rc = set_smem(kern, SL::BYTES, "attr(conv_fwd)"); if (rc) return rc; done = true; }
+  { int rc = set_smem(kern, SL::BYTES, "attr(conv_fwd)"); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, bias, pooled, amax,
                      g.Co, tiles_m, tiles_n, (K + BK - 1) / BK);
   return check_hip(hipGetLastError(), "conv_fwd launch");
@@ -101,19 +96,16 @@ static int launch_dgrad(const float* dp, const uint8_t* am, const float* wd, flo
   typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wd, g.CiP, g.CiP, K};
   const int tiles_m = (rows + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.CiP + Cfg::BN - 1) / Cfg::BN;
   const int slots = 256 * SL::WG_PER_CU, tiles = tiles_m * tiles_n;
-  const char* pt = getenv("VQA_PERSISTENT");
-  const bool persistent = pt && pt[0] == '1';   // see launch_fwd
+  const bool persistent = knobs().persistent == 1;   // see launch_fwd
   if (persistent) {
     auto pk = conv_dgrad_persistent_kernel<Cfg, U>;
-    static bool done2 = false;
-    if (!done2) { int rc = set_smem(pk, SL::BYTES, "attr(conv_dgrad_p)"); if (rc) return rc; done2 = true; }
+    { int rc = set_smem(pk, SL::BYTES, "attr(conv_dgrad_p)"); if (rc) return rc; }
     hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, dx,
                        g.CiP, tiles_m, tiles_n, (K + BK - 1) / BK);
     return check_hip(hipGetLastError(), "conv_dgrad_persistent launch");
   }
   auto kern = conv_dgrad_kernel<Cfg, U>;
-  static bool done = false;
-  if (!done) { int rc = set_smem(kern, SL::BYTES, "attr(conv_dgrad)"); if (rc) return rc; done = true; }
+  { int rc = set_smem(kern, SL::BYTES, "attr(conv_dgrad)"); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, dx, g.CiP, tiles_m,
                      tiles_n, (K + BK - 1) / BK);
   return check_hip(hipGetLastError(), "conv_dgrad launch");
@@ -133,13 +125,12 @@ static WgradPlan plan_wgrad(const ConvGeom& g) {
   // 128-row tiles fit exactly (9*CiP = 1152) two 128x128 workgroups per CU stay ahead (83.0 vs 79.4 %).
   // VQA_WGRAD_192=0 / 1 disables / forces it wherever 9*CiP % 192 == 0.
   {
-    const char* w192 = getenv("VQA_WGRAD_192");
+    const int w192 = knobs().wgrad_192, w384 = knobs().wgrad_384;
     const bool can = p.big && p.KI % 192 == 0 && g.CiP % BK == 0 && g.Co % BK == 0 && 2 * g.Wp >= BK;
-    if (can && (w192 ? w192[0] == '1' : p.bm == 96)) p.bm = 192;
+    if (can && (w192 >= 0 ? w192 == 1 : p.bm == 96)) p.bm = 192;
     // 9*CiP = 1152 (CiP = 128): three 384-row tiles (8 MFMA waves of 96x64, one workgroup per CU, 133 KB LDS) reload
     // the routed B operand 3x instead of 9x: 82.4 -> 86.6 % (same box).  VQA_WGRAD_384=0 / 1 disables / forces it.
-    const char* w384 = getenv("VQA_WGRAD_384");
-    if (can && p.KI % 384 == 0 && !(w192 && w192[0] == '1') && (w384 ? w384[0] == '1' : true)) p.bm = 384;
+    if (can && p.KI % 384 == 0 && w192 != 1 && (w384 >= 0 ? w384 == 1 : true)) p.bm = 384;
   }
   p.tiles_m = (p.KI + p.bm - 1) / p.bm;
   p.tiles_n = (g.Co + bn - 1) / bn;
@@ -164,8 +155,7 @@ static int launch_wgrad(const float* x, const float* dp, const uint8_t* am, floa
   typename WgradA<Cfg::NVA, Cfg::LT, U>::Params pa{x, wg, p.KI};
   typename WgradB<Cfg::NVB, Cfg::LT, U>::Params pb{dp, am, wg};
   auto kern = conv_wgrad_kernel<Cfg, U>;
-  static bool done = false;
-  if (!done) { int rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad)"); if (rc) return rc; done = true; }
+  { int rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad)"); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, slab,
                      bias_slab, p.tiles_m, p.tiles_n, p.nk, p.ks_per_split);
   return check_hip(hipGetLastError(), "conv_wgrad launch");
@@ -195,8 +185,8 @@ static int batch_chunk(int B, int H, int W, int CiP, int Co, int stride) {
   const int64_t by_rows = ((1LL << 31) / 4 - 1) / ((int64_t)H * W);
   if (by_rows < c) c = by_rows;
   if (c > B) c = B;
-  if (const char* e = getenv("VQA_CONV_CHUNK")) {   // tests: force small chunks on small tensors
-    const int64_t f = atoi(e);
+  {   // tests: force small chunks on small tensors (VQA_CONV_CHUNK)
+    const int64_t f = knobs().conv_chunk;
     if (f > 0 && f < c) c = f;
   }
   return (int)c;     // 0: a single image is already too large
@@ -234,11 +224,11 @@ static int fwd_chunk(const float* x, const float* wf, const float* bias, float* 
   // left the VALU: conv1 / conv2 forward 84.4 / 88.3 % against 82.7 / 84.7 % (4 loader waves) and 83.6 / 85.2 %
   // (8); on dgrad the gap is wider (72 / 81 % against 56 / 70 % and 66 / 75 %).  The 256-row kernels stay
   // selectable with VQA_BIG_TILES=1 (4 loader waves) / 3 (8) and are parity-tested that way.
-  const char* bt = getenv("VQA_BIG_TILES");
-  const bool many_rows = bt && bt[0] == '1';
+  const int bt = knobs().big_tiles;
+  const bool many_rows = bt == 1;
   // channel counts that are not multiples of BK take the general per-lane-tap loaders (one tile shape)
   if (CiP % BK != 0) return launch_fwd<Cfg128x64, false>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
-  if (bt && bt[0] == '3' && Co > 64) return launch_fwd<Cfg256x128L8, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
+  if (bt == 3 && Co > 64) return launch_fwd<Cfg256x128L8, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
   if (Co > 64) return many_rows ? launch_fwd<Cfg256x128, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream)
                                 : launch_fwd<Cfg128, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
   return launch_fwd<Cfg128x64, true>(x, wf, bias, pooled, argmax, g, (hipStream_t)stream);
@@ -266,15 +256,15 @@ static int dgrad_chunk(const float* dpooled, const uint8_t* argmax, const float*
   const ConvGeom g = make_geom(B, H, W, CiP, Co, stride);
   int rc = check_geom("vqa_conv3x3_dgrad", g);
   if (rc) return rc;
-  const char* bt = getenv("VQA_BIG_TILES");
-  const bool many_rows = bt && bt[0] == '1';   // opt-in only, see vqa_conv3x3_relu_pool_fwd
+  const int bt = knobs().big_tiles;
+  const bool many_rows = bt == 1;   // opt-in only, see vqa_conv3x3_relu_pool_fwd
   if (Co % BK != 0) return launch_dgrad<Cfg128x64, false>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
-  if (bt && bt[0] == '3')
+  if (bt == 3)
     return CiP > 64 ? launch_dgrad<Cfg256x128L8, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
                     : launch_dgrad<Cfg256x64L8, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
   if (CiP > 64) return many_rows ? launch_dgrad<Cfg256x128, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
                                  : launch_dgrad<Cfg128, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
-  if (bt && bt[0] == '0') return launch_dgrad<Cfg128x64, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
+  if (bt == 0) return launch_dgrad<Cfg128x64, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
   return many_rows ? launch_dgrad<Cfg256x64, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream)
                    : launch_dgrad<Cfg128x64L8, true>(dpooled, argmax, wd, dx, g, (hipStream_t)stream);
 }

@@ -89,34 +89,73 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
 }
 
 // ------------------------------------------------------------------ embedding + dropout + tanh
+// Token ids outside [0, V) (nn.Embedding raises for them, models/model.py:155) are COUNTED in *bad (device
+// int32, optional) and treated as a zero embedding row in forward and backward alike; the host mirror raises
+// from the counter (dl_vqa_amd/model.py).
 __global__ void embed_tanh_fwd_kernel(const int64_t* q, const float* emb, float* x, int B, int T, int E, int V,
-                                      float p, float inv_keep, uint64_t seed) {
-  const int64_t total = (int64_t)T * B * E;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int e = (int)(i % E);
-    const int64_t tb = i / E;
-    const int b = (int)(tb % B), t = (int)(tb / B);
-    int64_t tok = q[(int64_t)b * T + t];
-    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-    float v = emb[tok * E + e];
-    if (p > 0.f) v *= drop_scale(seed, ((uint64_t)b * T + t) * E + e, p, inv_keep);
-    x[i] = tanhf(v);
-  }
-}
-
-__global__ void embed_tanh_bwd_kernel(const int64_t* q, const float* x, const float* dx, float* demb, int B, int T,
-                                      int E, int V, float p, float inv_keep, uint64_t seed) {
+                                      float p, float inv_keep, uint64_t seed, int* bad) {
   const int64_t total = (int64_t)T * B * E;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(i % E);
     const int64_t tb = i / E;
     const int b = (int)(tb % B), t = (int)(tb / B);
     const int64_t tok = q[(int64_t)b * T + t];
-    if (tok <= 0 || tok >= V) continue;  // padding_idx = 0 receives no gradient
-    const float xv = x[i];
-    float g = dx[i] * (1.f - xv * xv);
-    if (p > 0.f) g *= drop_scale(seed, ((uint64_t)b * T + t) * E + e, p, inv_keep);
-    atomicAdd(demb + tok * E + e, g);
+    const bool ok = tok >= 0 && tok < V;
+    if (!ok && e == 0 && bad) atomicAdd(bad, 1);
+    float v = ok ? emb[tok * E + e] : 0.f;
+    if (p > 0.f) v *= drop_scale(seed, ((uint64_t)b * T + t) * E + e, p, inv_keep);
+    x[i] = tanhf(v);
+  }
+}
+
+// One workgroup per vocabulary row v: scans the B*T token slots in index order, collects the slots whose token
+// is v (ballot-ordered compaction through LDS) and adds their gradient rows in that fixed order, so the result
+// is bitwise reproducible (no float atomics); rows that no slot references -- and row 0, the padding index,
+// which receives no gradient -- are written as zeros, so demb needs no memset.
+__global__ __launch_bounds__(256) void embed_tanh_bwd_kernel(const int64_t* q, const float* x, const float* dx,
+                                                             float* demb, int B, int T, int E, int V, float p,
+                                                             float inv_keep, uint64_t seed) {
+  __shared__ int hits[256];
+  __shared__ int wcount[4];
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = B * T;
+  for (int e0 = 0; e0 < E; e0 += 1024) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (v != 0) {
+      for (int s0 = 0; s0 < N; s0 += 256) {
+        const int s = s0 + tid;
+        const bool hit = s < N && q[s] == (int64_t)v;
+        const int total = __syncthreads_count(hit);       // uniform; also fences the previous round's hits[]
+        if (total == 0) continue;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wcount[w];
+        if (hit) hits[base + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+        __syncthreads();
+        for (int h = 0; h < total; ++h) {
+          const int sl = hits[h];
+          const int b = sl / T, t = sl - b * T;
+          const int64_t row = ((int64_t)t * B + b) * E;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int e = e0 + tid + 256 * k;
+            if (e < E) {
+              const float xv = x[row + e];
+              float g = dx[row + e] * (1.f - xv * xv);
+              if (p > 0.f) g *= drop_scale(seed, ((uint64_t)b * T + t) * E + e, p, inv_keep);
+              acc[k] += g;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = e0 + tid + 256 * k;
+      if (e < E) demb[(int64_t)v * E + e] = acc[k];
+    }
   }
 }
 
@@ -519,21 +558,18 @@ int colsum_launch(const float* x, int64_t ld, const uint8_t* mask, int64_t rows,
   return check_hip(hipGetLastError(), "colsum_stage2 launch");
 }
 
-// out[g] += sum over a slice of b (grid (G, slices)); out is zeroed by the launcher.  The result is the
-// x_conv bias gradient, which is ~0 by construction (softmax shift invariance), so the float atomics'
-// summation order is immaterial.
-__global__ void sum_bgp_kernel(const float* x, float* out, int B, int G, int P) {
+// out[g] = sum_{b,p} x[b][g][p]: one 1024-thread workgroup per g, fixed summation order (deterministic).
+// (The result is the x_conv bias gradient, ~0 by construction: softmax is shift invariant.)
+__global__ __launch_bounds__(1024) void sum_bgp_kernel(const float* x, float* out, int B, int G, int P) {
   __shared__ float red[16];
   const int g = blockIdx.x;
-  const int per = (B + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   float s = 0.f;
-  for (int b = b0; b < b1; ++b) {
+  for (int b = 0; b < B; ++b) {
     const float* row = x + ((int64_t)b * G + g) * P;
     for (int i = threadIdx.x; i < P; i += blockDim.x) s += row[i];
   }
   s = block_reduce(s, red, false);
-  if (threadIdx.x == 0) atomicAdd(out + g, s);
+  if (threadIdx.x == 0) out[g] = s;
 }
 
 // out[b][n] = sum_r part[(b*parts + r)*cols + n]
@@ -628,18 +664,17 @@ int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, float* 
 }
 
 int vqa_embed_tanh_fwd(const int64_t* q, const float* emb, float* x, int B, int T, int E, int V, float p,
-                       uint64_t seed, vqa_stream_t stream) {
+                       uint64_t seed, int32_t* bad_tokens, vqa_stream_t stream) {
   VQA_REQUIRE(q && emb && x && B > 0 && T > 0 && E > 0 && V > 0, "vqa_embed_tanh_fwd: bad args");
   hipLaunchKernelGGL(embed_tanh_fwd_kernel, dim3(grid_for((int64_t)B * T * E, 256)), dim3(256), 0, STREAM, q, emb, x,
-                     B, T, E, V, p, KEEP(p), seed);
+                     B, T, E, V, p, KEEP(p), seed, bad_tokens);
   return check_hip(hipGetLastError(), "embed_tanh_fwd launch");
 }
 
 int vqa_embed_tanh_bwd(const int64_t* q, const float* x, const float* dx, float* demb, int B, int T, int E, int V,
                        float p, uint64_t seed, vqa_stream_t stream) {
-  VQA_REQUIRE(q && x && dx && demb, "vqa_embed_tanh_bwd: null pointer");
-  hipLaunchKernelGGL(embed_tanh_bwd_kernel, dim3(grid_for((int64_t)B * T * E, 256)), dim3(256), 0, STREAM, q, x, dx,
-                     demb, B, T, E, V, p, KEEP(p), seed);
+  VQA_REQUIRE(q && x && dx && demb && B > 0 && T > 0 && E > 0 && V > 0, "vqa_embed_tanh_bwd: bad args");
+  hipLaunchKernelGGL(embed_tanh_bwd_kernel, dim3(V), dim3(256), 0, STREAM, q, x, dx, demb, B, T, E, V, p, KEEP(p), seed);
   return check_hip(hipGetLastError(), "embed_tanh_bwd launch");
 }
 
@@ -741,9 +776,7 @@ int vqa_colsum(const float* x, int64_t ld, const uint8_t* mask, int64_t rows, in
 
 int vqa_sum_bgp(const float* x, float* out, int B, int G, int P, vqa_stream_t stream) {
   VQA_REQUIRE(x && out, "vqa_sum_bgp: null pointer");
-  int rc0 = check_hip(hipMemsetAsync(out, 0, (size_t)G * 4, STREAM), "sum_bgp memset");
-  if (rc0) return rc0;
-  hipLaunchKernelGGL(sum_bgp_kernel, dim3(G, B < 64 ? B : 64), dim3(256), 0, STREAM, x, out, B, G, P);
+  hipLaunchKernelGGL(sum_bgp_kernel, dim3(G), dim3(1024), 0, STREAM, x, out, B, G, P);
   return check_hip(hipGetLastError(), "sum_bgp launch");
 }
 

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 
 #include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include <type_traits>
@@ -21,6 +23,44 @@ int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return VQA_OK;
   set_error("%s: %s", what, hipGetErrorString(e));
   return VQA_ERR_HIP;
+}
+
+// ------------------------------------------------------------------ launch plumbing
+static std::mutex g_attr_mu;
+static std::set<std::pair<int, const void*>> g_attr_done;
+int ensure_dyn_smem(const void* kernel, int bytes, const char* what) {
+  int dev = 0;
+  int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_attr_mu);
+  if (g_attr_done.count({dev, kernel})) return VQA_OK;
+  rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
+  if (rc) return rc;
+  g_attr_done.insert({dev, kernel});
+  return VQA_OK;
+}
+
+static std::mutex g_knob_mu;
+static Knobs g_knobs;
+static bool g_knobs_read = false;
+static int env_int(const char* name) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : -1;
+}
+static void read_knobs_locked() {
+  g_knobs.split_target = env_int("VQA_SPLIT_TARGET");
+  g_knobs.big_tiles = env_int("VQA_BIG_TILES");
+  g_knobs.persistent = env_int("VQA_PERSISTENT");
+  g_knobs.weight_stationary = env_int("VQA_WEIGHT_STATIONARY");
+  g_knobs.wgrad_192 = env_int("VQA_WGRAD_192");
+  g_knobs.wgrad_384 = env_int("VQA_WGRAD_384");
+  g_knobs.conv_chunk = env_int("VQA_CONV_CHUNK");
+  g_knobs_read = true;
+}
+const Knobs& knobs() {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  if (!g_knobs_read) read_knobs_locked();
+  return g_knobs;
 }
 
 // ------------------------------------------------------------------ profiling hook
@@ -290,8 +330,8 @@ static GemmPlan plan_gemm(int M, int N, int K) {
   // Two workgroups fit a CU: 512 resident slots.  A launch that fills them exactly keeps two MFMA waves on
   // every SIMD (one covers the other's barriers); 384 workgroups left a quarter of the slots empty
   // (v_conv dW 0.90 -> 0.72 ms with 24 -> 32 splits), more than 512 would run a second, nearly empty round.
-  const char* st = getenv("VQA_SPLIT_TARGET");
-  const int target = st ? atoi(st) : 512;
+  const Knobs& kn = knobs();
+  const int target = kn.split_target > 0 ? kn.split_target : 512;
   if (t128 >= 200) {
     p.big = 1;
     // 200..511 big tiles with a long K: two splits double the resident workgroups (LSTM dW_hh: 256 tiles)
@@ -313,8 +353,7 @@ static GemmPlan plan_gemm(int M, int N, int K) {
   }
   // 256x128 tiles (8 MFMA waves, as the conv forward) measured 4-8 % SLOWER on the tall plain GEMMs
   // (v_conv fwd 1.29 vs 1.24 ms, dgrad 0.94 vs 0.87 ms): opt-in only (VQA_BIG_TILES=2)
-  const char* bt = getenv("VQA_BIG_TILES");
-  if (p.big && splits == 1 && bt && bt[0] == '2') p.big = 2;
+  if (p.big && splits == 1 && kn.big_tiles == 2) p.big = 2;
   const int bm = p.big == 2 ? 256 : (p.big ? 128 : 64), bn = p.big ? 128 : 64;
   p.tiles_m = (M + bm - 1) / bm;
   p.tiles_n = (N + bn - 1) / bn;
@@ -322,8 +361,7 @@ static GemmPlan plan_gemm(int M, int N, int K) {
   p.ks_per_split = (nk + splits - 1) / splits;
   p.splits = (nk + p.ks_per_split - 1) / p.ks_per_split;
   // skinny GEMM with a big B operand: keep each XCD on its own column slice of B (tile_coord order 1)
-  const char* wo = getenv("VQA_WEIGHT_STATIONARY");
-  p.order = (p.tiles_m <= 8 && p.tiles_n >= 16 && !(wo && wo[0] == '0')) ? 1 : 0;
+  p.order = (p.tiles_m <= 8 && p.tiles_n >= 16 && kn.weight_stationary != 0) ? 1 : 0;
   return p;
 }
 
@@ -336,18 +374,12 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
     // share of a tile's life: v_conv forward 1.13 -> 1.04 ms, LSTM input GEMM 0.116 -> 0.105 ms); with long K
     // the static tile striding loses more to imbalance than it saves (v_conv dgrad 0.82 -> 0.88 ms), so those
     // keep one workgroup per tile and the hardware's dynamic dispatch.  VQA_PERSISTENT=0/1 forces the choice.
-    const char* pt = getenv("VQA_PERSISTENT");
-    const bool persistent = pt ? pt[0] == '1' : p.nk <= 16;
+    const int pt = knobs().persistent;
+    const bool persistent = pt >= 0 ? pt == 1 : p.nk <= 16;
     if (p.splits == 1 && persistent) {
-      static bool attr2 = false;
       auto pk = gemm_persistent_kernel<Cfg, AL, BL>;
-      if (!attr2) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(pk),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SL::BYTES),
-                           "hipFuncSetAttribute(gemm_persistent)");
-        if (rc) return rc;
-        attr2 = true;
-      }
+      int rc = ensure_dyn_smem(reinterpret_cast<const void*>(pk), SL::BYTES, "hipFuncSetAttribute(gemm_persistent)");
+      if (rc) return rc;
       const int slots = 256 * SL::WG_PER_CU;
       const int tiles = p.tiles_m * p.tiles_n;
       hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, pe,
@@ -355,14 +387,10 @@ static int launch_gemm(const typename AL::Params& pa, const typename BL::Params&
       return check_hip(hipGetLastError(), "gemm_persistent_kernel launch");
     }
   }
-  static bool attr_done = false;
   auto kern = gemm_kernel<Cfg, AL, BL>;
-  if (!attr_done) {
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SL::BYTES),
-                       "hipFuncSetAttribute(gemm)");
+  {
+    int rc = ensure_dyn_smem(reinterpret_cast<const void*>(kern), SL::BYTES, "hipFuncSetAttribute(gemm)");
     if (rc) return rc;
-    attr_done = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n * p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, pe, p.tiles_m, p.tiles_n, p.nk,
@@ -400,6 +428,12 @@ int vqa_device_ok(void) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int vqa_reload_knobs(void) {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  read_knobs_locked();
+  return VQA_OK;
 }
 
 int vqa_prof_arm(int kernel_id, int tag) {

@@ -135,12 +135,9 @@ int vqa_lstm_step_fwd(const float* h_in, const float* w_hh, const float* xg_t, c
   typename PlainR<Cfg::NVA, Cfg::LT>::Params pa{h_in, (int64_t)H, B, H};
   typename LstmWhhR<Cfg::NVB, Cfg::LT>::Params pb{w_hh, H};
   const int tiles_m = (B + Cfg::BM - 1) / Cfg::BM, tiles_n = (4 * H + Cfg::BN - 1) / Cfg::BN;
-  static bool done = false;
-  if (!done) {
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SL::BYTES), "attr(lstm_step_fwd)");
+  {
+    int rc = ensure_dyn_smem(reinterpret_cast<const void*>(lstm_step_fwd_kernel), SL::BYTES, "attr(lstm_step_fwd)");
     if (rc) return rc;
-    done = true;
   }
   hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, (hipStream_t)stream,
                      pa, pb, xg_t, c_in, q_len, t, gates, c_out, h_out, c_final, cf_ld, B, H, tiles_m, tiles_n);

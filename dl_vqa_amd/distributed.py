@@ -46,6 +46,13 @@ class DataParallel:
             h.wait()                            # stream-ordered on NCCL: no host block
         self._handles = []
 
+    def reduce_flat(self, flat: torch.Tensor) -> None:
+        """SUM all-reduce of a whole gradient buffer in one piece: the path backward takes when it could not
+        write into the model's own flat buffer (gradient accumulation, several forwards per backward), where
+        the per-bucket overlap does not apply.  Every micro-step's contribution is reduced on its own, so the
+        accumulated p.grad is the reduced sum."""
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+
     def __call__(self, *args, **kwargs):
         return self.model(*args, **kwargs)
 

@@ -105,8 +105,17 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, P: Dict[str, Tensor], v: Tensor, q: Tensor, q_len: Tensor, training: bool, seed: int,
-                keep: bool):
-        """Returns (logits [B,A], ctx or None). `keep` = save what backward needs."""
+                keep: bool, bad_tokens: Optional[Tensor] = None):
+        """Returns (logits [B,A], ctx or None). `keep` = save what backward needs.
+        bad_tokens: optional device int32 [1] that counts token ids outside the vocabulary."""
+        # kernels launch on HIP's CURRENT device and torch's current stream of that device: make the tensors'
+        # device current for the whole schedule (a model on cuda:1 while cuda:0 is current would otherwise
+        # launch on GPU 0 with GPU-1 pointers)
+        with torch.cuda.device(v.device):
+            return self._forward(P, v, q, q_len, training, seed, keep, bad_tokens)
+
+    def _forward(self, P: Dict[str, Tensor], v: Tensor, q: Tensor, q_len: Tensor, training: bool, seed: int,
+                 keep: bool, bad_tokens: Optional[Tensor] = None):
         assert v.is_cuda and v.dtype == torch.float32 and v.dim() == 4, "v must be a float32 CUDA tensor [B,C,S,S]"
         v = v.contiguous()
         q = q.to(device=v.device, dtype=torch.int64).contiguous()
@@ -120,7 +129,7 @@ class Engine:
 
         # ---- question encoder (model.py:155-166)
         p_txt = self.p_text if tr else 0.0
-        x_emb = ops.embed_tanh_fwd(q, P["text.embedding.weight"], p_txt, sd(SITE_TEXT))       # [T,B,E]
+        x_emb = ops.embed_tanh_fwd(q, P["text.embedding.weight"], p_txt, sd(SITE_TEXT), bad_tokens)       # [T,B,E]
         combined = new(B, Dc)
         lstm = [None] * self.ndir
 
@@ -150,7 +159,9 @@ class Engine:
             lstm[d] = SimpleNamespace(gates=gates, Hs=Hs, Cs=Cs, xg=xg, hg=hg)
 
         # The question branch is a chain of small (M = B) launches, independent of the image branch until the
-        # attention stage: each LSTM direction runs on its own side stream, under the convolutions.
+        # attention stage: each LSTM direction runs on its own side stream.  Default schedule (VQA_STREAMS=1): the
+        # two directions overlap EACH OTHER and the main stream waits for both before the convolutions start;
+        # VQA_STREAMS=2 lets them run under the convolutions as well (measured no gain: the convs fill the chip).
         main = torch.cuda.current_stream(dev)
         sides = self._side_streams(dev)
         fork = torch.cuda.Event()
@@ -246,6 +257,10 @@ class Engine:
         `on_ready(group)` is called after the kernels producing a parameter group have been enqueued
         ('classifier', 'attention', 'text', 'image'): the data-parallel wrapper starts that bucket's
         all-reduce there, overlapping the rest of backward."""
+        with torch.cuda.device(dlogits.device):
+            self._backward(P, ctx, dlogits, Gr, on_ready)
+
+    def _backward(self, P, ctx, dlogits, Gr, on_ready):
         B, T, Pn = ctx.B, ctx.T, ctx.Pn
         E, H, G, C, mid, hid, A, Dc, GC, Q = self.E, self.H, self.G, self.C, self.mid, self.hid, self.A, self.Dc, self.GC, self.Q
         dev = dlogits.device
@@ -336,9 +351,10 @@ class Engine:
             ops.gemm(dgates, w_ih, dx_parts[d], T * B, E, 4 * H, transB=False, lda=4 * H, ldb=E, tag=53)
             st.dgates = dgates          # keep alive until the streams have joined
 
-        # BPTT of each direction on its side stream, concurrently with the convolution backward on the main
-        # stream; direction 0's stream finishes the question branch (joins direction 1, embedding gradient)
-        # and hands the 'text' bucket to the data-parallel hook from there, so its all-reduce also overlaps.
+        # BPTT of each direction on its own side stream; direction 0's stream finishes the question branch (joins
+        # direction 1, embedding gradient) and hands the 'text' bucket to the data-parallel hook from there.  In the
+        # default schedule (VQA_STREAMS=1) the main stream waits for the question branch before the convolution
+        # backward, so only the 'text' all-reduce (not BPTT) overlaps the convolutions; VQA_STREAMS=2 drops that wait.
         main = torch.cuda.current_stream(dev)
         sides = self._side_streams(dev)
         fork = torch.cuda.Event()
@@ -357,8 +373,7 @@ class Engine:
             if ev1 is not None:
                 sides[0].wait_event(ev1)
                 ops.add(dx_parts[0], dx_parts[1], dx_emb)
-            demb = Gr["text.embedding.weight"]
-            demb.zero_()
+            demb = Gr["text.embedding.weight"]       # every row is written (deterministic per-row sums)
             ops.embed_tanh_bwd(ctx.q, ctx.x_emb, dx_emb, demb, ctx.p_txt, sd(SITE_TEXT))
             ready("text")
             ev0 = torch.cuda.Event()

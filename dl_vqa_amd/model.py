@@ -13,6 +13,7 @@ gradients) so that the optimiser and the data-parallel all-reduce work on contig
 """
 from __future__ import annotations
 
+import weakref
 from collections import OrderedDict
 from typing import Dict, List, Optional
 
@@ -94,31 +95,51 @@ def _flat_order(names: List[str]) -> List[str]:
     return sorted(names, key=key)
 
 
-GROUP_OF = {"classifier": "classifier", "attention": "attention", "text": "text", "image": "image"}
-
-
 class _VqaFunction(torch.autograd.Function):
+    """Autograd node of one VqaNet.forward call.
+
+    Gradient storage: the model owns ONE flat gradient buffer (`_flat_grad`) that the fused optimiser
+    and the data-parallel buckets work on.  backward writes into it directly -- and starts each
+    bucket's all-reduce from inside backward -- only when that is safe: no parameter holds a gradient
+    yet and no other forward of this module is still waiting for its backward (two forwards inside
+    one graph would otherwise overwrite each other's gradients in place and autograd would then add
+    two aliases of the same memory).  In every other case (gradient accumulation,
+    ``zero_grad(set_to_none=False)``, several forwards per backward) the gradients go to a fresh
+    buffer that autograd accumulates as usual; under data parallelism that buffer is all-reduced
+    before it is handed to autograd, so replicas never step on unreduced gradients.
+    """
+
     @staticmethod
     def forward(ctx, model, v, q, q_len, seed, *params):
         P = model._param_dict()
-        logits, saved = model._engine.forward(P, v, q, q_len, model.training, seed, keep=True)
+        logits, saved = model._engine.forward(P, v, q, q_len, model.training, seed, keep=True,
+                                              bad_tokens=model._bad_tokens)
         ctx.model = model
         ctx.saved = saved
         model._last_ctx = saved
+        model._pending.add(ctx)          # weak: a graph that is dropped without backward leaves the set
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         model = ctx.model
+        if ctx.saved is None:
+            raise RuntimeError("dl_vqa_amd.VqaNet: backward through the same forward twice (the saved "
+                               "activations are released after the first backward; retain_graph is not supported)")
         names = model._names
-        accumulate_safe = all(p.grad is None for p in model._params)
-        Gr = model._grad_views(fresh=not accumulate_safe)
-        sync = model._grad_sync if accumulate_safe else None
-        on_ready = (lambda group: sync.bucket_ready(model, group)) if sync is not None else None
+        others = [c for c in model._pending if c is not ctx]
+        direct = not others and all(p.grad is None for p in model._params)
+        flat, Gr = model._grad_buffer(fresh=not direct)
+        sync = model._grad_sync
+        on_ready = (lambda group: sync.bucket_ready(model, group)) if (sync is not None and direct) else None
         model._engine.backward(model._param_dict(), ctx.saved, dlogits, Gr, on_ready)
         if sync is not None:
-            sync.finish(model)
+            if direct:
+                sync.finish(model)
+            else:
+                sync.reduce_flat(flat)
         ctx.saved = None
+        model._pending.discard(ctx)
         return (None, None, None, None, None) + tuple(Gr[n] for n in names)
 
 
@@ -156,7 +177,10 @@ class VqaNet(nn.Module):
         self._grad_sync = None          # set by dl_vqa_amd.distributed.DataParallel
         self._last_ctx = None
         self._seed_rank = 0
-        self._fwd_calls = 0
+        self._pending = weakref.WeakSet()   # autograd nodes of forwards whose backward has not run yet
+        self._bad_tokens = None             # device counter of out-of-vocabulary token ids (+ pinned host copy, event)
+        self._bad_host = None
+        self._bad_event = None
 
     # ------------------------------------------------------------------ flat parameter storage
     def _flatten(self, device):
@@ -195,13 +219,17 @@ class VqaNet(nn.Module):
     def _param_dict(self) -> Dict[str, torch.Tensor]:
         return {n: p.data for n, p in zip(self._names, self._params)}
 
-    def _grad_views(self, fresh: bool = False) -> Dict[str, torch.Tensor]:
+    def _grad_buffer(self, fresh: bool = False):
+        """(flat buffer, {name: view}) -- the model's own flat gradient buffer, or a fresh one of the same layout."""
         flat = torch.zeros_like(self._flat_grad) if fresh else self._flat_grad
         out = {}
         for n, p in zip(self._names, self._params):
             o, numel = self._offsets[n]
             out[n] = flat[o:o + numel].view(p.shape)
-        return out
+        return flat, out
+
+    def _grad_views(self, fresh: bool = False) -> Dict[str, torch.Tensor]:
+        return self._grad_buffer(fresh)[1]
 
     def flat_buffers(self):
         """(flat parameters, flat gradients, {name: (offset, numel)}) — used by the fused optimiser and DP."""
@@ -221,10 +249,54 @@ class VqaNet(nn.Module):
         s = int(torch.empty((), dtype=torch.int64).random_().item())
         return (s ^ (self._seed_rank * 0x5851F42D4C957F2D)) & ((1 << 63) - 1)
 
+    # ------------------------------------------------------------------ token-id validation
+    # nn.Embedding raises for ids outside [0, V) (models/model.py:155).  Ids that arrive on the host are checked
+    # there; ids already on the device are counted by the embedding kernel and the count is read back without
+    # blocking: the error surfaces at the next forward (or at check_token_ids(), which synchronises) -- the
+    # same deferred reporting a device-side assert has.
+    def _validate_tokens(self, q):
+        V = self._engine.V
+        if not q.is_cuda:
+            if q.numel() and (int(q.min()) < 0 or int(q.max()) >= V):
+                raise IndexError(f"question token id out of range [0, {V}) (nn.Embedding would raise: models/model.py:155)")
+            return
+        self._raise_if_bad(block=False)
+        dev = q.device
+        if self._bad_tokens is None or self._bad_tokens.device != dev:
+            self._bad_tokens = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._bad_event = None
+
+    def _after_forward_tokens(self, q):
+        if q.is_cuda and self._bad_tokens is not None:
+            self._bad_host.copy_(self._bad_tokens, non_blocking=True)
+            self._bad_event = torch.cuda.Event()
+            self._bad_event.record(torch.cuda.current_stream(q.device))
+
+    def _raise_if_bad(self, block: bool):
+        ev = self._bad_event
+        if ev is None:
+            return
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._bad_event = None
+        n = int(self._bad_host[0])
+        if n:
+            self._bad_tokens.zero_()
+            raise IndexError(f"{n} question token id(s) out of range [0, {self._engine.V}) in an earlier forward "
+                             "(nn.Embedding would raise: models/model.py:155); they were embedded as zeros")
+
+    def check_token_ids(self):
+        """Synchronise and raise IndexError if a forward so far saw a token id outside the vocabulary."""
+        self._raise_if_bad(block=True)
+
     def forward(self, v, q, q_len):
         self._ensure_flat()
         if not v.is_cuda:
             raise RuntimeError("dl_vqa_amd.VqaNet.forward needs CUDA (HIP) tensors; there is no CPU fallback")
+        self._validate_tokens(q)
         if v.dtype == torch.float16:
             # the dataset's storage format (preprocessing/preprocess_images.py:39-53): widen on the device
             from . import ops
@@ -232,6 +304,9 @@ class VqaNet(nn.Module):
         seed = self._next_seed() if self.training else 0
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._params)
         if need_grad:
-            return _VqaFunction.apply(self, v, q, q_len, seed, *self._params)
-        logits, _ = self._engine.forward(self._param_dict(), v, q, q_len, self.training, seed, keep=False)
+            logits = _VqaFunction.apply(self, v, q, q_len, seed, *self._params)
+        else:
+            logits, _ = self._engine.forward(self._param_dict(), v, q, q_len, self.training, seed, keep=False,
+                                             bad_tokens=self._bad_tokens)
+        self._after_forward_tokens(q)
         return logits

@@ -142,11 +142,13 @@ def l2norm_bwd(dvn, vn, norm, p: float, seed: int, out=None):
     return d
 
 
-def embed_tanh_fwd(q: torch.Tensor, emb: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+def embed_tanh_fwd(q: torch.Tensor, emb: torch.Tensor, p: float, seed: int,
+                   bad_tokens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bad_tokens: optional device int32 [1], incremented once per token id outside [0, V)."""
     B, T = q.shape
     V, E = emb.shape
     x = torch.empty(T, B, E, dtype=torch.float32, device=emb.device)
-    call("vqa_embed_tanh_fwd", ptr(q), ptr(emb), ptr(x), B, T, E, V, p, seed, stream())
+    call("vqa_embed_tanh_fwd", ptr(q), ptr(emb), ptr(x), B, T, E, V, p, seed, ptr(bad_tokens), stream())
     return x
 
 

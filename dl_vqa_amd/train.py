@@ -1,20 +1,19 @@
-"""Host-side mirror of the reference training procedure (train.py:18-208, utils/train_utils.py).
+"""The per-batch half of the reference training procedure on the device (train.py:172-208,
+utils/train_utils.py:12-25, train.py:31-35,55,80).
 
-Same function names and argument meaning as the reference so its loop is drop-in:
-``run_batch(model, log_softmax, batch_data, max_answers)``, ``evaluate``, ``train``,
-``update_learning_rate``, ``TrainParams``, ``batch_accuracy``.  What differs is where the work
-runs: the soft-target cross entropy, its gradient and the VQA score are one HIP kernel on the
-device (the reference builds numpy index arrays on the host and syncs B+1 times per step,
-train.py:195-199, train_utils.py:19-23), and Adam is one fused kernel over the flat parameter
-buffer (train.py:55,80).
+``run_batch(model, log_softmax, batch_data, max_answers)``, ``batch_accuracy`` and
+``update_learning_rate`` keep the reference's names and argument meaning, so the reference's own
+epoch loop (train.py:38-169: ``train`` / ``evaluate``, out of scope here and not restated) calls
+them unchanged.  What differs is where the work runs: the soft-target cross entropy, its gradient
+and the VQA score are one HIP kernel on the device (the reference builds numpy index arrays on
+the host and syncs B+1 times per step, train.py:195-199, train_utils.py:19-23), and ``FusedAdam``
+is torch.optim.Adam's update as one kernel over the flat parameter buffer (train.py:55,80).
 """
 from __future__ import annotations
 
-import time
-from typing import Dict, Optional
+from typing import Optional
 
 import torch
-import torch.nn as nn
 
 from . import ops
 
@@ -112,11 +111,30 @@ class FusedAdam:
         return flat_p, flat_g
 
     def zero_grad(self, set_to_none: bool = True):
+        """Always drops the gradients (set_to_none=False is accepted and treated the same): backward then
+        writes the next gradients straight into the flat buffer instead of accumulating."""
         for p in self.model.parameters():
             p.grad = None
 
+    def _gather_grads(self, flat_g):
+        """The kernel reads the model's flat gradient buffer.  After a plain backward every p.grad IS a view
+        of it; after gradient accumulation (or anything else that made autograd allocate its own p.grad) the
+        gradients are copied into their slots first."""
+        _, _, offsets = self.model.flat_buffers()
+        named = list(self.model.named_parameters())
+        missing = [n for n, p in named if p.grad is None]
+        if missing:
+            raise RuntimeError(f"FusedAdam.step: parameters without a gradient ({missing[:3]}...): run backward first "
+                               "(torch.optim.Adam would skip them; the fused kernel updates the whole buffer)")
+        base = flat_g.data_ptr()
+        for n, p in named:
+            o, k = offsets[n]
+            if p.grad.data_ptr() != base + 4 * o or not p.grad.is_contiguous():
+                flat_g[o:o + k].view(p.shape).copy_(p.grad)
+
     def step(self, grad_scale: float = 1.0):
         flat_p, flat_g = self._state()
+        self._gather_grads(flat_g)
         g = self.param_groups[0]
         self.step_count += 1
         ops.adam(flat_p, flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], self.step_count, g["betas"][0],
@@ -154,102 +172,3 @@ class FusedAdam:
             self.step_count = int(float(st["step"]))
         g = sd["param_groups"][0]
         self.param_groups[0].update(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"])
-
-
-# ------------------------------------------------------------------ train / evaluate
-class TrainParams:
-    """utils/train_utils.py:58-80."""
-
-    def __init__(self, **kwargs):
-        self.n_epochs_stop = kwargs["n_epochs_stop"]
-        self.num_epochs = kwargs["num_epochs"]
-        self.lr = kwargs["lr"]["lr_value"]
-        self.lr_decay = kwargs["lr"]["lr_decay"]
-        self.lr_gamma = kwargs["lr"]["lr_gamma"]
-        self.lr_step_size = kwargs["lr"]["lr_step_size"]
-        self.save_model = kwargs["save_model"]
-        self.max_answers = kwargs["max_answers"]
-
-
-def get_train_params(cfg) -> TrainParams:
-    return TrainParams(**cfg["train"])
-
-
-def get_zeroed_metrics_dict() -> Dict:
-    return {"train_loss": 0, "train_score": 0, "total_norm": 0, "count_norm": 0}
-
-
-def get_metrics(best_eval_score, eval_score, train_loss):
-    return {"Metrics/BestAccuracy": best_eval_score, "Metrics/LastAccuracy": eval_score,
-            "Metrics/LastLoss": train_loss}
-
-
-class _NullLogger:
-    def write(self, *a, **k): pass
-    def write_epoch_statistics(self, **k): print(k)
-    def report_scalars(self, *a, **k): pass
-    def report_scalars_same_plot(self, *a, **k): pass
-    def save_model(self, *a, **k): pass
-
-
-def train(model: nn.Module, train_loader, eval_loader, train_params: TrainParams, logger=None,
-          optimizer_stuff: Optional[dict] = None, world_size: int = 1):
-    """Training procedure with the control flow of the reference (train.py:38-141)."""
-    logger = logger if logger is not None else _NullLogger()
-    total_iterations = 0
-    best_eval_score = torch.tensor(0.0)
-    epochs_no_improve = 0
-    optimizer = FusedAdam(model, lr=train_params.lr)
-    if optimizer_stuff:
-        optimizer.load_state_dict(optimizer_stuff)
-    metrics = get_zeroed_metrics_dict()
-    for epoch in range(train_params.num_epochs):
-        t = time.time()
-        metrics = get_zeroed_metrics_dict()
-        for batch_data in train_loader:
-            divisor = batch_data[0].shape[0] * world_size
-            batch_loss, batch_score = run_batch(model, None, batch_data, train_params.max_answers, divisor)
-            optimizer.zero_grad()
-            update_learning_rate(optimizer=optimizer, iteration=total_iterations, initial_lr=train_params.lr)
-            batch_loss.backward()
-            optimizer.step()
-            total_iterations += 1
-            metrics["train_score"] += batch_score.detach()
-            metrics["train_loss"] += batch_loss.detach()
-        metrics["train_loss"] /= len(train_loader)
-        metrics["train_score"] /= len(train_loader.dataset)
-        metrics["train_score"] *= 100
-        model.train(False)
-        metrics["eval_score"], metrics["eval_loss"] = evaluate(model, eval_loader, train_params.max_answers)
-        model.train(True)
-        epoch_time = time.time() - t
-        logger.write_epoch_statistics(epoch=epoch, epoch_time=epoch_time, train_loss=metrics["train_loss"], norm=0,
-                                      train_score=metrics["train_score"], eval_score=metrics["eval_score"])
-        logger.report_scalars({"Accuracy/Train": metrics["train_score"], "Accuracy/Validation": metrics["eval_score"],
-                               "Loss/Train": metrics["train_loss"], "Loss/Validation": metrics["eval_loss"]}, epoch)
-        if metrics["eval_score"] > best_eval_score:
-            epochs_no_improve = 0
-            best_eval_score = metrics["eval_score"]
-            if train_params.save_model:
-                logger.save_model(model, epoch, optimizer)
-        else:
-            epochs_no_improve += 1
-        if epoch > 3 and epochs_no_improve == train_params.n_epochs_stop:
-            logger.write("Early stopping!")
-            break
-    return get_metrics(best_eval_score, metrics["eval_score"], metrics["train_loss"])
-
-
-@torch.no_grad()
-def evaluate(model: nn.Module, dataloader, max_answers):
-    """train.py:144-169: (accuracy in percent, mean loss) over a loader, no gradients."""
-    score = torch.tensor(0.0)
-    loss = 0
-    for batch_data in dataloader:
-        batch_loss, batch_score = run_batch(model, None, batch_data, max_answers)
-        loss += batch_loss
-        score = score.to(batch_score.device) + batch_score
-    loss /= len(dataloader)
-    score /= len(dataloader.dataset)
-    score *= 100
-    return score, loss

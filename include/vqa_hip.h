@@ -9,8 +9,9 @@
  *     the library never allocates, frees or synchronises;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
  *   - return value: 0 = success, otherwise a VQA_ERR_* code; vqa_last_error() gives the text;
- *   - no C++ exception crosses the ABI; functions are stateless and re-entrant apart from the
- *     optional profiling hook;
+ *   - no C++ exception crosses the ABI; functions are re-entrant (safe from any host thread, any device);
+ *     the only state is the optional profiling hook, the VQA_* knobs (read once) and a per-device record of
+ *     kernels whose LDS limit has been raised, all behind mutexes;
  *   - all floating point is IEEE fp32; contractions use v_mfma_f32_32x32x2_f32 (exact fp32);
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS; pointers and leading
  *     dimensions of GEMM operands must be multiples of 4 elements (16-byte vector loads);
@@ -38,6 +39,10 @@ int vqa_abi_version(void);
 const char* vqa_last_error(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never fails). */
 int vqa_device_ok(void);
+
+/* Re-read the VQA_* environment knobs (forced tile variants for parity tests, diagnostics).  They are read
+ * once when the library is first used; tests that switch variants inside one process call this. */
+int vqa_reload_knobs(void);
 
 /* ---- profiling hook (bench.py: live HIP-event timing of one kernel family) ------------------ */
 enum {
@@ -118,10 +123,13 @@ int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, float* 
                    int C, float p, uint64_t seed, vqa_stream_t stream);
 
 /* ---- question encoder (models/model.py:134-166 questionNet) ----------------------------------
- * x[t][b][:] = tanh(dropout(emb[q[b][t]]))   (embedding -> drop -> tanh, model.py:155-157) */
+ * x[t][b][:] = tanh(dropout(emb[q[b][t]]))   (embedding -> drop -> tanh, model.py:155-157).
+ * Token ids outside [0, V) -- nn.Embedding raises for them -- are counted into *bad_tokens (device int32,
+ * may be NULL; the caller zeroes and reads it) and contribute a zero row, forward and backward alike. */
 int vqa_embed_tanh_fwd(const int64_t* q, const float* emb, float* x, int B, int T, int E, int V,
-                       float p, uint64_t seed, vqa_stream_t stream);
-/* demb[q[b][t]] += dx * (1 - x^2) * dropmask, token 0 skipped (padding_idx=0). demb pre-zeroed. */
+                       float p, uint64_t seed, int32_t* bad_tokens, vqa_stream_t stream);
+/* demb[v][:] = sum over the slots (b,t) with q[b][t] == v of dx * (1 - x^2) * dropmask, in slot order
+ * (deterministic, no atomics); every row of demb [V][E] is WRITTEN (row 0 = padding_idx and unused rows: zeros). */
 int vqa_embed_tanh_bwd(const int64_t* q, const float* x, const float* dx, float* demb, int B, int T,
                        int E, int V, float p, uint64_t seed, vqa_stream_t stream);
 /* One LSTM time step for one direction (gate order i,f,g,o; nn.LSTM, model.py:145-149):

@@ -44,16 +44,30 @@ def conv_relu_pool(x: Tensor, w: Tensor, b: Tensor, stride: int = 1) -> Tensor:
     return F.max_pool2d(y, 2, 2)
 
 
+# Dropout (7 sites, model.py:84,156,185,186,194,201,204).  torch's RNG stream cannot be reproduced off-torch, so
+# train mode is restated with the masks as DATA: `masks[site]` is the keep-scale tensor (0 or 1/(1-p)) of a site,
+# multiplied in exactly where the reference applies nn.Dropout; a missing key / masks=None is eval mode.
+#   "image" [B,C,g,g]   "text" [B,T,E]   "att_v" [B,C,g,g]   "att_q" [B,Q]   "att_x" [B,mid or 2*mid,g,g]
+#   "cls1" [B,G*C+Q]    "cls2" [B,hid]
+MASK_SITES = ("image", "text", "att_v", "att_q", "att_x", "cls1", "cls2")
+
+
+def _drop(x: Tensor, masks: Optional[dict], site: str) -> Tensor:
+    if masks is None or masks.get(site) is None:
+        return x
+    return x * masks[site].to(x.dtype)
+
+
 def image_encoder(sd: Dict[str, Tensor], v: Tensor, stride: int = 1,
-                  stages: Optional[dict] = None) -> Tensor:
-    """ImageNet2.forward in eval mode (model.py:79-84; dropout is identity)."""
+                  stages: Optional[dict] = None, masks: Optional[dict] = None) -> Tensor:
+    """ImageNet2.forward (model.py:79-84): the conv blocks, then image.drop on the last pooled map."""
     i = 0
     while f"image.conv{i}.weight" in sd:
         v = conv_relu_pool(v, sd[f"image.conv{i}.weight"], sd[f"image.conv{i}.bias"], stride)
         if stages is not None:
             stages[f"pool{i}"] = v
         i += 1
-    return v
+    return _drop(v, masks, "image")                                  # model.py:84
 
 
 def l2_normalise(v: Tensor) -> Tensor:
@@ -93,14 +107,14 @@ def lstm_direction(x: Tensor, q_len: Tensor, w_ih: Tensor, w_hh: Tensor,
 
 
 def question_encoder(sd: Dict[str, Tensor], q: Tensor, q_len: Tensor,
-                     bidirectional: bool = True) -> Tensor:
-    """questionNet.forward in eval mode: embedding(pad 0) -> tanh -> LSTM -> c_n.
+                     bidirectional: bool = True, masks: Optional[dict] = None) -> Tensor:
+    """questionNet.forward: embedding(pad 0) -> dropout -> tanh -> LSTM -> c_n.
 
     Returns [B, 2H] = [c_fwd | c_bwd]  (model.py:164-166: c_n.transpose(0,1).flatten(1)).
     """
     emb = sd["text.embedding.weight"]
     # padding_idx=0 (model.py:138-140): row 0 is read as stored but receives no gradient
-    x = torch.tanh(F.embedding(q, emb, padding_idx=0))       # model.py:155-157
+    x = torch.tanh(_drop(F.embedding(q, emb, padding_idx=0), masks, "text"))       # model.py:155-157
     outs = []
     _, c = lstm_direction(x, q_len, sd["text.lstm.weight_ih_l0"], sd["text.lstm.weight_hh_l0"],
                           sd["text.lstm.bias_ih_l0"], sd["text.lstm.bias_hh_l0"], False)
@@ -117,11 +131,12 @@ def question_encoder(sd: Dict[str, Tensor], q: Tensor, q_len: Tensor,
 # --------------------------------------------------------------------------
 # attention — reference models/model.py:169-195, 208-231
 # --------------------------------------------------------------------------
-def attention_scores(sd: Dict[str, Tensor], v: Tensor, q: Tensor, do_option: str = "+") -> Tensor:
-    """Attention.forward in eval mode (model.py:183-195).  v [B,C,g,g], q [B,Q] -> [B,G,g,g]."""
+def attention_scores(sd: Dict[str, Tensor], v: Tensor, q: Tensor, do_option: str = "+",
+                     masks: Optional[dict] = None) -> Tensor:
+    """Attention.forward (model.py:183-195).  v [B,C,g,g], q [B,Q] -> [B,G,g,g]."""
     wv = sd["attention.v_conv.weight"]          # [mid, C, 1, 1], no bias (model.py:173)
-    vv = torch.einsum("bchw,mc->bmhw", v, wv[:, :, 0, 0])
-    qq = q @ sd["attention.q_lin.weight"].t() + sd["attention.q_lin.bias"]
+    vv = torch.einsum("bchw,mc->bmhw", _drop(v, masks, "att_v"), wv[:, :, 0, 0])                  # model.py:185
+    qq = _drop(q, masks, "att_q") @ sd["attention.q_lin.weight"].t() + sd["attention.q_lin.bias"]  # model.py:186
     qq = qq[:, :, None, None].expand_as(vv)     # tile_question_over_image (model.py:224-231)
     if do_option == "*":
         x = torch.relu(vv * qq)
@@ -132,6 +147,7 @@ def attention_scores(sd: Dict[str, Tensor], v: Tensor, q: Tensor, do_option: str
     else:
         raise ValueError(do_option)
     wx = sd["attention.x_conv.weight"][:, :, 0, 0]
+    x = _drop(x, masks, "att_x")                                                                     # model.py:194
     return torch.einsum("bmhw,gm->bghw", x, wx) + sd["attention.x_conv.bias"][None, :, None, None]
 
 
@@ -147,21 +163,22 @@ def image_question_attention(v: Tensor, att: Tensor) -> Tuple[Tensor, Tensor]:
     return out, p
 
 
-def classifier(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
-    """Classifier in eval mode: Linear -> ReLU -> Linear (model.py:198-205)."""
-    h = torch.relu(x @ sd["classifier.lin1.weight"].t() + sd["classifier.lin1.bias"])
-    return h @ sd["classifier.lin2.weight"].t() + sd["classifier.lin2.bias"]
+def classifier(sd: Dict[str, Tensor], x: Tensor, masks: Optional[dict] = None) -> Tensor:
+    """Classifier: Dropout -> Linear -> ReLU -> Dropout -> Linear (model.py:198-205)."""
+    h = torch.relu(_drop(x, masks, "cls1") @ sd["classifier.lin1.weight"].t() + sd["classifier.lin1.bias"])
+    return _drop(h, masks, "cls2") @ sd["classifier.lin2.weight"].t() + sd["classifier.lin2.bias"]
 
 
 def vqa_forward(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: Tensor,
-                stages: Optional[dict] = None) -> Tensor:
-    """VqaNet.forward in eval mode (model.py:53-67). Returns logits [B, max_answers]."""
-    img = image_encoder(sd, v, cfg["image"]["stride"], stages)
+                stages: Optional[dict] = None, masks: Optional[dict] = None) -> Tensor:
+    """VqaNet.forward (model.py:53-67). Returns logits [B, max_answers].
+    masks=None: eval mode; masks = {site: keep-scale tensor}: train mode with those dropout masks (MASK_SITES)."""
+    img = image_encoder(sd, v, cfg["image"]["stride"], stages, masks)
     vn = l2_normalise(img)
-    qf = question_encoder(sd, q, q_len, cfg["text"]["bidirectional"])
-    att = attention_scores(sd, vn, qf, cfg["attention"]["do_option"])
-    wv, probs = image_question_attention(vn, att)
-    logits = classifier(sd, torch.cat([wv, qf], dim=1))
+    qf = question_encoder(sd, q, q_len, cfg["text"]["bidirectional"], masks)
+    att = attention_scores(sd, vn, qf, cfg["attention"]["do_option"], masks)
+    wv, probs = image_question_attention(vn, att)              # the weighted sum sees v WITHOUT attention.drop
+    logits = classifier(sd, torch.cat([wv, qf], dim=1), masks)
     if stages is not None:
         stages.update(image=img, vnorm=vn, question=qf, attention=att, probs=probs,
                       weighted=wv, logits=logits)
@@ -214,14 +231,14 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
 # --------------------------------------------------------------------------
 def loss_and_grads(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: Tensor,
                    a_indices: Tensor, a_values: Tensor,
-                   loss_scale_batch: Optional[int] = None
+                   loss_scale_batch: Optional[int] = None, masks: Optional[dict] = None
                    ) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
     """Forward + soft-CE + backward by autograd over the restated ops.
 
     ``loss_scale_batch`` overrides the divisor B (used by the data-parallel
-    tests, where each rank divides by the GLOBAL batch)."""
+    tests, where each rank divides by the GLOBAL batch); ``masks``: train mode, see vqa_forward."""
     params = {k: t.detach().clone().requires_grad_(True) for k, t in sd.items()}
-    logits = vqa_forward(params, cfg, v, q, q_len)
+    logits = vqa_forward(params, cfg, v, q, q_len, masks=masks)
     loss = soft_ce_loss(logits, a_indices, a_values)
     if loss_scale_batch is not None:
         loss = loss * (logits.shape[0] / float(loss_scale_batch))

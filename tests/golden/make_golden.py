@@ -10,6 +10,11 @@ What is recorded (data only: inputs and expected outputs, no reference source):
       inputs, the full state_dict, per-stage activations, logits, loss, VQA score
       and the gradient of every parameter, all produced by the imported
       ``models.model.VqaNet`` in eval mode (dropout = identity) with autograd.
+  tiny_{plus,mul,cat}_train.npz
+      the same model in TRAIN mode with the dropout masks as recorded data: each nn.Dropout instance of the
+      reference model is swapped for a module that multiplies by the next recorded keep-scale mask
+      (Bernoulli(1-p)/(1-p), p = 0.3), so WHERE each mask is applied is decided by the reference's own
+      forward (models/model.py:84,156,185,186,194,201,204).  Fixture: masks per site, logits, loss, gradients.
   full224_seed1.npz
       the north-star architecture (channels [3,64,128,256], E=300, H=1024, mid=1024,
       G=2, A=1000, V=5000) at S=224, B=2, T=14.  The 18.7 M parameters are not
@@ -99,8 +104,8 @@ def make_inputs(B, S, T, V, A, q_len, seed):
     return v, q, q_len, a_idx, a_val, a_len
 
 
-def run_reference(model, v, q, q_len, a_idx, a_val, a_len, capture=True):
-    model.eval()
+def run_reference(model, v, q, q_len, a_idx, a_val, a_len, capture=True, train=False):
+    model.train(train)
     stages = {}
     hooks = []
     if capture:
@@ -148,6 +153,60 @@ def tiny_case(name, do_option="+", stride=1, bidirectional=True, S=32, seed=1):
     print(name, "loss", float(loss), "score", float(score), "logits[0,:3]", y[0, :3].tolist())
 
 
+class MaskDrop(torch.nn.Module):
+    """Stand-in for one nn.Dropout INSTANCE of the reference model: call k multiplies by the k-th recorded mask."""
+
+    def __init__(self, masks):
+        super().__init__()
+        self.masks, self.calls = masks, 0
+
+    def forward(self, x):
+        m = self.masks[self.calls]
+        self.calls += 1
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return x * m
+
+
+def train_case(name, do_option="+", S=32, seed=1, p=0.3):
+    cfg = tiny_cfg(do_option, 1, True)
+    V, A, B, T = 50, cfg["max_answers"], 3, 5
+    torch.manual_seed(seed)
+    model = VqaNet(cfg, V)
+    v, q, q_len, a_idx, a_val, a_len = make_inputs(B, S, T, V, A, [5, 3, 1], seed + 100)
+    q[0, 2] = 0
+    ch, E, H = cfg["image"]["num_channels"], cfg["text"]["embedding_features"], cfg["text"]["question_features"]
+    mid, G, hid = cfg["attention"]["hidden_dim"], cfg["attention"]["glimpses"], cfg["classifier"]["hidden_dim"]
+    g = S
+    for _ in range(3):
+        g = (g - 2) // 2
+    C, Q = ch[-1], 2 * H
+    gen = torch.Generator().manual_seed(seed + 500)
+    mk = lambda *shape: (torch.rand(*shape, generator=gen) >= p).float() / (1.0 - p)
+    masks = {"image": mk(B, C, g, g), "text": mk(B, T, E), "att_v": mk(B, C, g, g), "att_q": mk(B, Q),
+             "att_x": mk(B, 2 * mid if do_option == "|" else mid, g, g), "cls1": mk(B, G * C + Q), "cls2": mk(B, hid)}
+    # one stand-in per nn.Dropout instance; attention.drop is called three times: on v, on q, on x (model.py:185,186,194)
+    model.image.drop = MaskDrop([masks["image"]])
+    model.text.drop = MaskDrop([masks["text"]])
+    model.attention.drop = MaskDrop([masks["att_v"], masks["att_q"], masks["att_x"]])
+    model.classifier.drop1 = MaskDrop([masks["cls1"]])
+    model.classifier.drop2 = MaskDrop([masks["cls2"]])
+    y, loss, score, grads, _ = run_reference(model, v, q, q_len, a_idx, a_val, a_len, capture=False, train=True)
+    assert model.attention.drop.calls == 3 and model.image.drop.calls == 1 and model.classifier.drop2.calls == 1
+    out = {"v": v, "q": q, "q_len": q_len, "a_idx": a_idx, "a_val": a_val, "a_len": a_len,
+           "logits": y, "loss": loss, "score": score}
+    for k, t in model.state_dict().items():
+        out["sd/" + k] = t
+    for k, t in grads.items():
+        out["grad/" + k] = t
+    for k, t in masks.items():
+        out["mask/" + k] = t
+    meta = dict(do_option=do_option, stride=1, bidirectional=True, S=S, V=V, seed=seed, p=p)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        **{k: t.numpy() for k, t in out.items()},
+                        meta=np.array(repr(meta)))
+    print(name, "loss", float(loss), "score", float(score), "logits[0,:3]", y[0, :3].tolist())
+
+
 def full_case(seed=1):
     cfg = full_cfg()
     V, A, B, T, S = 5000, 1000, 2, 14, 224
@@ -179,6 +238,10 @@ def full_case(seed=1):
 
 
 if __name__ == "__main__":
+    if "--train-only" in sys.argv:      # add the train-mode fixtures without rewriting the others
+        for nm, op in (("tiny_plus_train", "+"), ("tiny_mul_train", "*"), ("tiny_cat_train", "|")):
+            train_case(nm, op)
+        sys.exit(0)
     tiny_case("tiny_plus", "+")
     tiny_case("tiny_mul", "*")
     tiny_case("tiny_cat", "|")
@@ -186,4 +249,6 @@ if __name__ == "__main__":
     tiny_case("tiny_uni", "+", bidirectional=False)
     # odd intermediate sizes like the north-star shapes (62->31, 29->14, 12->6)
     tiny_case("small64_plus", "+", S=64, seed=3)
+    for nm, op in (("tiny_plus_train", "+"), ("tiny_mul_train", "*"), ("tiny_cat_train", "|")):
+        train_case(nm, op)
     full_case()

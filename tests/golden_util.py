@@ -8,6 +8,8 @@ import torch
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TINY_CASES = ["tiny_plus", "tiny_mul", "tiny_cat", "tiny_stride2", "tiny_uni", "small64_plus"]
+# reference model in train mode with the dropout masks recorded as data (make_golden.train_case)
+TRAIN_CASES = ["tiny_plus_train", "tiny_mul_train", "tiny_cat_train"]
 
 
 def tiny_cfg(meta):
@@ -39,7 +41,7 @@ class Golden:
         z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
         self.meta = ast.literal_eval(str(z["meta"]))
         self.raw = z
-        self.sd, self.grad, self.stage, self.t = {}, {}, {}, {}
+        self.sd, self.grad, self.stage, self.t, self.mask = {}, {}, {}, {}, {}
         for k in z.files:
             if k == "meta" or z[k].dtype.kind in "US":
                 continue
@@ -50,6 +52,8 @@ class Golden:
                 self.grad[k[5:]] = t
             elif k.startswith("stage/"):
                 self.stage[k[6:]] = t
+            elif k.startswith("mask/"):
+                self.mask[k[5:]] = t
             else:
                 self.t[k] = t
 

@@ -26,6 +26,20 @@ def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
     return float((got - ref).abs().max()) / scale
 
 
+@pytest.fixture
+def knob(monkeypatch):
+    """Set VQA_* environment knobs for one test: the library reads them once, so it is told to re-read them
+    (vqa_reload_knobs) after every change and again when the test's environment has been restored."""
+    from dl_vqa_amd import _lib
+
+    def set_knob(name, value):
+        monkeypatch.setenv(name, value)
+        _lib.load().vqa_reload_knobs()
+    yield set_knob
+    monkeypatch.undo()
+    _lib.load().vqa_reload_knobs()
+
+
 def check(name, got, ref, tol):
     e = rel_err(got, ref)
     print(f"[parity] {name}: max|err|/max|ref| = {e:.3e} (tol {tol:.1e})")
@@ -239,13 +253,41 @@ def test_embed_tanh_fwd_bwd():
     xr = torch.tanh(F.embedding(q, er, padding_idx=0)).transpose(0, 1)   # [T,B,E]
     dx = torch.randn(T, B, E, generator=g)
     xr.backward(dx.double())
-    x = ops.embed_tanh_fwd(q.to(DEV), emb.to(DEV), 0.0, 0)
-    demb = torch.zeros(V, E, device=DEV)
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    x = ops.embed_tanh_fwd(q.to(DEV), emb.to(DEV), 0.0, 0, bad)
+    demb = torch.full((V, E), 7.0, device=DEV)          # every row is written: no pre-zeroing needed
     ops.embed_tanh_bwd(q.to(DEV), x, dx.to(DEV), demb, 0.0, 0)
     torch.cuda.synchronize()
     check("embed fwd", x, xr, 2e-6)
     check("embed bwd", demb, er.grad, 5e-6)
-    assert float(demb[0].abs().max()) == 0.0
+    assert float(demb[0].abs().max()) == 0.0 and int(bad) == 0
+
+
+def test_embed_bwd_is_deterministic_and_counts_bad_tokens():
+    """Many slots per vocabulary row (B*T >> V, more than one 256-slot scan round, > 256 hits of one token in a
+    round impossible by construction): the per-row sums run in slot order, so two launches agree bit for bit;
+    ids outside [0, V) are counted, read as a zero row and receive no gradient."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    V, E, B, T = 7, 300, 150, 9
+    emb = torch.randn(V, E, generator=g)
+    q = torch.randint(0, V, (B, T), generator=g)
+    q[3, 2], q[10, 0], q[11, 8] = V, -1, V + 5
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    x = ops.embed_tanh_fwd(q.to(DEV), emb.to(DEV), 0.0, 0, bad)
+    dx = torch.randn(T, B, E, generator=g)
+    d1, d2 = torch.empty(V, E, device=DEV), torch.empty(V, E, device=DEV)
+    ops.embed_tanh_bwd(q.to(DEV), x, dx.to(DEV), d1, 0.0, 0)
+    ops.embed_tanh_bwd(q.to(DEV), x, dx.to(DEV), d2, 0.0, 0)
+    torch.cuda.synchronize()
+    assert int(bad) == 3 and torch.equal(d1, d2)
+    ok = (q >= 0) & (q < V)
+    qs = torch.where(ok, q, torch.zeros_like(q))
+    er = emb.double().requires_grad_(True)
+    xr = (torch.tanh(F.embedding(qs, er, padding_idx=0)) * ok[..., None]).transpose(0, 1)
+    xr.backward(dx.double())
+    check("embed fwd (bad ids -> zero rows)", x, xr, 2e-6)
+    check("embed bwd (deterministic)", d1, er.grad, 1e-5)
 
 
 def test_lstm_cell_fwd_bwd():
@@ -466,7 +508,7 @@ def test_conv0_dedicated_fwd_wgrad(B, Ci, H, W, Co):
 
 
 # ----------------------------------------------------------------------------- every tile configuration
-def test_conv_batch_chunking(monkeypatch):
+def test_conv_batch_chunking(knob):
     """Batches whose tensors would pass 4 GiB are walked in chunks inside the C ABI (32-bit offsets per launch);
     VQA_CONV_CHUNK forces that path on small tensors: forward and dgrad are bit-identical to one launch, wgrad's
     chunks are extra split-K slabs of the same reduce."""
@@ -488,7 +530,7 @@ def test_conv_batch_chunking(monkeypatch):
         return pooled, am, dw, db, dx
 
     ref = run()
-    monkeypatch.setenv("VQA_CONV_CHUNK", "2")      # 2 + 2 + 1 images
+    knob("VQA_CONV_CHUNK", "2")      # 2 + 2 + 1 images
     got = run()
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and torch.equal(ref[4], got[4])
     check("chunked wgrad dw", got[2], ref[2].double(), 1e-5)
@@ -496,19 +538,19 @@ def test_conv_batch_chunking(monkeypatch):
 
 
 @pytest.mark.parametrize("w192,w384", [("0", "0"), ("1", "0"), ("0", "1")])
-def test_wgrad_tall_tiles_forced(w192, w384, monkeypatch):
+def test_wgrad_tall_tiles_forced(w192, w384, knob):
     """The tall wgrad tiles (192x128 where 9*CiP = 576, 384x128 where 9*CiP = 1152: 8 MFMA waves, one workgroup
     per CU) and the 96- / 128-row tiles they replace are all parity-checked: the two variables force every choice."""
-    monkeypatch.setenv("VQA_WGRAD_192", w192)
-    monkeypatch.setenv("VQA_WGRAD_384", w384)
+    knob("VQA_WGRAD_192", w192)
+    knob("VQA_WGRAD_384", w384)
     test_conv_relu_pool_fwd_bwd(2, 58, 58, 64, 128, 1)
     test_conv_relu_pool_fwd_bwd(1, 30, 30, 128, 256, 1)
 
 
 @pytest.mark.parametrize("persistent", ["0", "1"])
-def test_persistent_tiles_forced(persistent, monkeypatch):
+def test_persistent_tiles_forced(persistent, knob):
     """VQA_PERSISTENT forces the persistent-tile kernels (normally chosen for short-K GEMMs only) on or off."""
-    monkeypatch.setenv("VQA_PERSISTENT", persistent)
+    knob("VQA_PERSISTENT", persistent)
     test_conv_relu_pool_fwd_bwd(2, 58, 58, 64, 128, 1)
     test_conv_relu_pool_fwd_bwd(3, 31, 29, 3, 8, 1)
     test_gemm_layouts(1030, 260, 3584, False, True)
@@ -517,11 +559,11 @@ def test_persistent_tiles_forced(persistent, monkeypatch):
 
 
 @pytest.mark.parametrize("big", ["0", "1", "2", "3"])
-def test_tile_configurations_forced(big, monkeypatch):
+def test_tile_configurations_forced(big, knob):
     """The 256-row / 8-MFMA-wave tile configurations are normally chosen by problem size (only the bench
     shapes reach them); VQA_BIG_TILES forces each choice so that every compiled kernel is parity-checked:
     0 = 128-row tiles everywhere, 1 = 256x128 / 256x64 conv forward + dgrad, 2 = 256x128 generic GEMM, 3 = 256-row conv forward + dgrad tiles with 8 loader waves (1024 threads)."""
-    monkeypatch.setenv("VQA_BIG_TILES", big)
+    knob("VQA_BIG_TILES", big)
     test_conv_relu_pool_fwd_bwd(2, 58, 58, 64, 128, 1)
     test_conv_relu_pool_fwd_bwd(1, 30, 30, 128, 256, 1)
     test_conv_relu_pool_fwd_bwd(2, 40, 40, 64, 64, 1)

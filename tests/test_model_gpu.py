@@ -144,6 +144,77 @@ def test_full224_reference_logits_and_gradients():
         assert e < 2e-3 and e2 < 1e-3, (n, e, e2)
 
 
+def test_long_questions_3000_answers_match_oracle():
+    """BASELINE configs[4] shapes on the text / classifier side (config/config.yaml:74 max_answers = 3000, 30-token
+    questions, ragged lengths incl. 1 and 30) with the north-star widths (E=300, H=1024, mid=1024) on 64x64 images."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    cfg = full_cfg(3000)
+    V, B, S, T = 5000, 5, 64, 30
+    torch.manual_seed(4)
+    m = build(cfg, V).eval()
+    v, q, a_idx, a_val, _, _, ql = O.synthetic_batch(B, S, T, V, 3000, seed=6)
+    ql = torch.tensor([30, 1, 17, 30, 8])
+    q = q * (torch.arange(T)[None, :] < ql[:, None])
+    q[0, 4] = 0                                        # padding / unknown token inside a question
+    sd = {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}
+    y_ref, loss_ref, grads_ref = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val)
+    y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
+    loss, _ = soft_ce_loss_and_score(y, a_idx.to(DEV), a_val.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    err = float((y.detach().cpu() - y_ref).abs().max())
+    print(f"[parity] T=30 A=3000 logits max abs err {err:.3e}; loss {float(loss):.6f} vs {float(loss_ref):.6f}")
+    assert y.shape == (B, 3000) and err < 1e-3 and err < 1e-5
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k, p in m.named_parameters():
+        e = grad_err(k, p.grad, grads_ref[k])
+        print(f"[parity] T=30 A=3000 grad {k}: {e:.3e}")
+        assert e < 2e-4, (k, e)
+
+
+def test_headline_batch_256_is_batch_invariant():
+    """BASELINE configs[1] at its real size: B=256, 224x224, T=14, A=1000, eval mode.  The batch is the two
+    samples of the reference fixture full224_seed1 repeated 128 times, so every logits row must equal the
+    reference's row for that sample and every parameter gradient (a mean over the batch) must equal the B=2
+    gradient the reference produced -- which pins the tile plans, split counts and grids that only run at full
+    size (plan_wgrad's splits, xcd_swizzle over 10^4+ workgroups, the 192-/384-row wgrad tiles, the LSTM step
+    kernel at M=256) without any CPU computation at B=256."""
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    g = Golden("full224_seed1")
+    meta = g.meta
+    torch.manual_seed(meta["seed"])
+    m = build(full_cfg(meta["A"]), meta["V"]).eval()
+    v, q, ql, a_idx, a_val, _ = full_inputs(meta)
+    R = 128
+    rep = lambda t: t.repeat(R, *([1] * (t.dim() - 1))).to(DEV)
+    y = m(rep(v), rep(q), rep(ql))
+    loss, score = soft_ce_loss_and_score(y, rep(a_idx), rep(a_val))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert y.shape == (2 * R, meta["A"])
+    ref = g.t["logits"].repeat(R, 1)
+    err = float((y.detach().cpu() - ref).abs().max())
+    print(f"[parity] B=256 logits max abs err {err:.3e}; loss {float(loss):.6f} vs {float(g.t['loss']):.6f}")
+    assert err < 1e-3
+    assert float((y[0::2] - y[0]).abs().max()) < 1e-5 and float((y[1::2] - y[1]).abs().max()) < 1e-5
+    assert abs(float(loss) - float(g.t["loss"])) < 1e-4
+    gnames = [str(n) for n in g.raw["grad_names"]]
+    grads = dict((k, p.grad) for k, p in m.named_parameters())
+    for n, l2 in zip(gnames, g.raw["grad_l2"]):
+        if n == ZERO_GRAD:
+            assert float(grads[n].abs().max()) < 1e-6
+            continue
+        flat = grads[n].flatten().double().cpu()
+        step = max(1, flat.numel() // 257)
+        sample = flat[::step][:257]
+        refg = torch.from_numpy(g.raw["gsample/" + n]).double()
+        e = float((sample - refg).abs().max()) / max(float(refg.abs().max()), 1e-30)
+        e2 = abs(float(flat.pow(2).sum().sqrt()) - l2) / max(l2, 1e-30)
+        print(f"[parity] B=256 grad {n}: sample {e:.3e} l2 {e2:.3e}")
+        assert e < 2e-3 and e2 < 1e-3, (n, e, e2)
+
+
 def test_matches_cpu_oracle_on_random_batch():
     """A shape no fixture covers (B=5, S=48, T=7 ragged lengths): HIP vs the oracle run in float64."""
     from oracle import vqa_oracle as O
@@ -240,12 +311,124 @@ def test_fused_adam_step_matches_oracle_and_checkpoint_format():
     assert opt2.step_count == 1 and torch.equal(opt2.exp_avg, opt.exp_avg)
 
 
+def test_two_forwards_before_one_backward_match_oracle():
+    """(loss(model(a)) + loss(model(b))).backward() -- the second backward must not overwrite the
+    first one's gradients in the shared flat buffer; and a later FusedAdam.step must see the accumulated sum."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd.train import FusedAdam, soft_ce_loss_and_score
+    g = Golden("tiny_plus")
+    cfg = tiny_cfg(g.meta)
+    m = build(cfg, g.meta["V"], g.sd).eval()
+    b1 = O.synthetic_batch(3, 32, 5, g.meta["V"], 12, seed=21)
+    b2 = O.synthetic_batch(4, 32, 6, g.meta["V"], 12, seed=22)
+
+    def hip_loss(b):
+        v, q, a_idx, a_val, _, _, ql = b
+        return soft_ce_loss_and_score(m(v.to(DEV), q.to(DEV), ql.to(DEV)), a_idx.to(DEV), a_val.to(DEV))[0]
+
+    (hip_loss(b1) + hip_loss(b2)).backward()
+    torch.cuda.synchronize()
+    refs = [O.loss_and_grads(g.sd, cfg, b[0], b[1], b[6], b[2], b[3])[2] for b in (b1, b2)]
+    for k, p in m.named_parameters():
+        assert grad_err(k, p.grad, refs[0][k] + refs[1][k]) < 2e-4, k
+    opt = FusedAdam(m, lr=1e-3)
+    opt.step()                                          # gathers p.grad into the flat buffer first
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        o, n = m._offsets[k]
+        assert torch.equal(m._flat_grad[o:o + n].view(p.shape), p.grad), k
+
+
+def test_out_of_vocabulary_token_ids_raise():
+    """nn.Embedding raises for ids outside [0, V) (models/model.py:155): host-resident ids are checked before the
+    upload, device-resident ids are counted by the kernel and reported at check_token_ids() / the next forward."""
+    g = Golden("tiny_plus")
+    m = build(tiny_cfg(g.meta), g.meta["V"], g.sd).eval()
+    v, q, ql = g.t["v"].to(DEV), g.t["q"].clone(), g.t["q_len"].to(DEV)
+    q[1, 0] = g.meta["V"]
+    with torch.no_grad():
+        with pytest.raises(IndexError, match="out of range"):
+            m(v, q, ql)                                  # q on the host
+        y = m(v, q.to(DEV), ql)                          # q on the device: counted, embedded as zeros
+        assert bool(torch.isfinite(y).all())
+        with pytest.raises(IndexError, match="1 question token"):
+            m.check_token_ids()
+        m(v, g.t["q"].to(DEV), ql)                       # valid ids: nothing pending afterwards
+        m.check_token_ids()
+
+
 def test_cpu_tensors_are_rejected():
     cfg = tiny_cfg(dict(bidirectional=True, stride=1, do_option="+"))
     from dl_vqa_amd import VqaNet
     m = VqaNet(cfg, 30)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.randn(1, 3, 32, 32), torch.ones(1, 4, dtype=torch.int64), torch.tensor([4]))
+
+
+@pytest.mark.parametrize("do_option", ["+", "*", "|"])
+def test_train_mode_matches_oracle_with_shared_masks(do_option):
+    """Train mode (all 7 dropout sites, p = 0.3) against the oracle: the masks the HIP kernels generate are
+    extracted as data (tests/hip_masks.py) and given to the oracle, whose mask PLACEMENT is pinned by
+    reference-generated train-mode fixtures (tests/test_oracle_golden.py::test_train_mode_with_recorded_masks).
+    Logits within 1e-3 (north star), every gradient within 2e-4 relative."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    from tests.hip_masks import hip_masks
+    g = Golden({"+": "tiny_plus", "*": "tiny_mul", "|": "tiny_cat"}[do_option])
+    cfg = tiny_cfg(g.meta)
+    m = build(cfg, g.meta["V"], g.sd).train()
+    v, q, ql = g.t["v"], g.t["q"], g.t["q_len"]
+    torch.manual_seed(123)
+    y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
+    loss, _ = soft_ce_loss_and_score(y, g.t["a_idx"].to(DEV), g.t["a_val"].to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ctx = m._last_ctx
+    assert ctx.p_att == 0.3 and ctx.seed != 0
+    masks = hip_masks(m._engine, ctx.seed, v.shape[0], q.shape[1], ctx.acts[-1].shape[1], DEV)
+    for k, mk in masks.items():      # real masks: values in {0, 1/(1-p)}, both present
+        vals = set(round(float(x), 4) for x in mk.unique())
+        assert vals == {0.0, round(1 / 0.7, 4)}, (k, vals)
+    y_ref, loss_ref, grads_ref = O.loss_and_grads(g.sd, cfg, v, q, ql, g.t["a_idx"], g.t["a_val"], masks=masks)
+    err = float((y.detach().cpu() - y_ref).abs().max())
+    print(f"[parity] train-mode ({do_option}) logits max abs err {err:.3e}; loss {float(loss):.6f} vs {float(loss_ref):.6f}")
+    assert err < 1e-3 and err < 2e-5
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    y_eval = O.vqa_forward(g.sd, cfg, v, q, ql)
+    assert float((y_ref - y_eval).abs().max()) > 1e-2          # the masks matter: eval-mode logits are far away
+    for k, p in m.named_parameters():
+        e = grad_err(k, p.grad, grads_ref[k], "+")             # in train mode q_lin's gradient is not zero for '|'
+        print(f"[parity] train-mode ({do_option}) grad {k}: {e:.3e}")
+        assert e < 2e-4, (k, e)
+
+
+def test_train_mode_full224_matches_oracle_with_shared_masks():
+    """The north-star architecture (224x224, B=2, T=14, A=1000) in train mode, HIP vs oracle with shared masks."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    from tests.hip_masks import hip_masks
+    g = Golden("full224_seed1")
+    meta = g.meta
+    torch.manual_seed(meta["seed"])
+    cfg = full_cfg(meta["A"])
+    m = build(cfg, meta["V"]).train()
+    sd = {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}
+    v, q, ql, a_idx, a_val, _ = full_inputs(meta)
+    y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
+    loss, _ = soft_ce_loss_and_score(y, a_idx.to(DEV), a_val.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ctx = m._last_ctx
+    masks = hip_masks(m._engine, ctx.seed, 2, q.shape[1], ctx.acts[-1].shape[1], DEV)
+    y_ref, loss_ref, grads_ref = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks)
+    err = float((y.detach().cpu() - y_ref).abs().max())
+    print(f"[parity] train-mode full224 logits max abs err {err:.3e}; loss {float(loss):.6f} vs {float(loss_ref):.6f}")
+    assert err < 1e-3
+    assert abs(float(loss) - float(loss_ref)) < 1e-4
+    for k, p in m.named_parameters():
+        e = grad_err(k, p.grad, grads_ref[k], "+")
+        print(f"[parity] train-mode full224 grad {k}: {e:.3e}")
+        assert e < 1e-3, (k, e)        # fp32 both sides, K up to 6.4e5 products per element in the conv wgrads
 
 
 @pytest.mark.parametrize("do_option", ["+", "*", "|"])

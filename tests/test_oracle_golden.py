@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from oracle import vqa_oracle as O
-from tests.golden_util import TINY_CASES, Golden, tiny_cfg
+from tests.golden_util import TINY_CASES, TRAIN_CASES, Golden, tiny_cfg
 
 
 @pytest.mark.parametrize("name", TINY_CASES)
@@ -32,6 +32,26 @@ def test_loss_score_grads(name):
         torch.testing.assert_close(grads[k], g.grad[k], rtol=2e-4, atol=2e-6, msg=lambda m: f"{k}: {m}")
     # padding / unknown-token row of the embedding gets no gradient
     assert float(grads["text.embedding.weight"][0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_train_mode_with_recorded_masks(name):
+    """Dropout placement: the reference model ran in train mode with every nn.Dropout fed a recorded mask
+    (tests/golden/make_golden.py: train_case); the oracle given the same masks must reproduce its logits, loss
+    and every gradient -- and must NOT when a mask is withheld (the fixture really exercises every site)."""
+    g = Golden(name)
+    cfg = tiny_cfg(g.meta)
+    assert set(g.mask) == set(O.MASK_SITES)
+    y, loss, grads = O.loss_and_grads(g.sd, cfg, g.t["v"], g.t["q"], g.t["q_len"], g.t["a_idx"], g.t["a_val"],
+                                      masks=g.mask)
+    torch.testing.assert_close(y, g.t["logits"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss, g.t["loss"], rtol=1e-5, atol=1e-6)
+    for k in grads:
+        torch.testing.assert_close(grads[k], g.grad[k], rtol=2e-4, atol=2e-6, msg=lambda m: f"{k}: {m}")
+    for site in O.MASK_SITES:
+        partial = {k: v for k, v in g.mask.items() if k != site}
+        y2 = O.vqa_forward(g.sd, cfg, g.t["v"], g.t["q"], g.t["q_len"], masks=partial)
+        assert float((y2 - g.t["logits"]).abs().max()) > 1e-4, f"site {site} has no effect on the logits"
 
 
 def test_float64_oracle_close_to_fp32_reference():

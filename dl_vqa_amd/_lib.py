@@ -45,12 +45,14 @@ PROTOTYPES = {
     "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
     "vqa_lstm_cell_bwd": (i32, [f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, i32, i32, vp]),
     "vqa_lstm_step_supported": (i32, [i32]),
-    "vqa_lstm_step_fwd": (i32, [f32p, f32p, f32p, f32p, vp, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
+    "vqa_lstm_seq_fwd": (i32, [vp, i32, i64p, i32, i32, i32, i64, i32, vp]),
+    "vqa_lstm_seq_bwd": (i32, [vp, i32, i64p, i32, i32, i32, i32, vp]),
+    "vqa_lstm_graph_stats": (i32, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "vqa_att_score_fwd": (i32, [f32p, f32p, i32, f32p, f32p, i32, i32, i32, i32, f32, u64, f32p, vp]),
     "vqa_att_row_splits": (i32, [i32]),
     "vqa_att_score_bwd": (i32, [f32p, f32p, i32, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, i32, f32p, f32p, vp]),
     "vqa_att_apply_fwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, i32, i32, i32, vp]),
-    "vqa_att_apply_bwd": (i32, [f32p, i64, f32p, f32p, f32p, f32p, i32, i32, i32, i32, vp]),
+    "vqa_att_apply_bwd": (i32, [f32p, i64, f32p, f32p, f32p, f32p, f32p, i32, i32, i32, i32, vp]),
     "vqa_softce_fwd_bwd": (i32, [f32p, i64, i64p, i64p, i32, i32, i32, f32, f32p, f32p, f32p, i64, vp]),
     "vqa_colsum_workspace_bytes": (i64, [i64, i32]),
     "vqa_colsum": (i32, [f32p, i64, u8p, i64, i32, f32p, i32, f32p, i64, vp]),
@@ -64,6 +66,12 @@ PROTOTYPES = {
 }
 
 K_GEMM, K_CONV_FWD, K_CONV_DGRAD, K_CONV_WGRAD = 0, 1, 2, 3
+
+
+class LstmDir(C.Structure):
+    """vqa_lstm_dir_t (include/vqa_hip.h): one direction of an LSTM sequence, device pointers as integers."""
+    _fields_ = [("w_hh", vp), ("xg", vp), ("gates", vp), ("Hs", vp), ("Cs", vp), ("c_final", vp),
+                ("dgates", vp), ("dh", vp), ("dc", vp), ("reverse", i32)]
 
 
 class VqaHipError(RuntimeError):

@@ -441,13 +441,23 @@ __global__ void att_apply_bwd_rows_kernel(const float* dout, int64_t dout_ld, co
   }
 }
 // pass 2: block per (b,g): dscore = probs * (dprob - sum_p probs*dprob), in place on dprob
-__global__ void softmax_bwd_kernel(const float* probs, float* dscore, int P) {
+// rowsum (optional) [B*G]: sum_p dscore of the block's row -- the per-sample part of the x_conv bias gradient
+__global__ void softmax_bwd_kernel(const float* probs, float* dscore, int P, float* rowsum) {
   __shared__ float red[16];
   const int64_t base = (int64_t)blockIdx.x * P;
   float s = 0.f;
   for (int i = threadIdx.x; i < P; i += blockDim.x) s += probs[base + i] * dscore[base + i];
   s = block_reduce(s, red, false);
-  for (int i = threadIdx.x; i < P; i += blockDim.x) dscore[base + i] = probs[base + i] * (dscore[base + i] - s);
+  float t = 0.f;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    const float d = probs[base + i] * (dscore[base + i] - s);
+    dscore[base + i] = d;
+    t += d;
+  }
+  if (rowsum) {
+    t = block_reduce(t, red, false);
+    if (threadIdx.x == 0) rowsum[blockIdx.x] = t;
+  }
 }
 
 // ------------------------------------------------------------------ soft-target CE + VQA score
@@ -558,15 +568,17 @@ int colsum_launch(const float* x, int64_t ld, const uint8_t* mask, int64_t rows,
   return check_hip(hipGetLastError(), "colsum_stage2 launch");
 }
 
-// out[g] = sum_{b,p} x[b][g][p]: one 1024-thread workgroup per g, fixed summation order (deterministic).
+// out[g] = sum_{b,p} x[b][g][p], deterministic two-stage sum inside one launch-pair-free kernel: grid (G), 1024
+// threads; thread groups of 64 lanes take whole rows [b][g][:] (coalesced), partial sums combine in a fixed order.
 // (The result is the x_conv bias gradient, ~0 by construction: softmax is shift invariant.)
 __global__ __launch_bounds__(1024) void sum_bgp_kernel(const float* x, float* out, int B, int G, int P) {
   __shared__ float red[16];
   const int g = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;     // 16 waves, wave w takes samples w, w+16, ...
   float s = 0.f;
-  for (int b = 0; b < B; ++b) {
+  for (int b = w; b < B; b += 16) {
     const float* row = x + ((int64_t)b * G + g) * P;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) s += row[i];
+    for (int i = lane; i < P; i += 64) s += row[i];
   }
   s = block_reduce(s, red, false);
   if (threadIdx.x == 0) out[g] = s;
@@ -744,14 +756,14 @@ int vqa_att_apply_fwd(const float* score, const float* vn, float* probs, float* 
 }
 
 int vqa_att_apply_bwd(const float* dout, int64_t dout_ld, const float* probs, const float* vn, float* dscore,
-                      float* dvn, int B, int P, int C, int G, vqa_stream_t stream) {
+                      float* dvn, float* dscore_rowsum, int B, int P, int C, int G, vqa_stream_t stream) {
   VQA_REQUIRE(dout && probs && vn && dscore && dvn && C % 4 == 0 && dout_ld % 4 == 0, "vqa_att_apply_bwd: bad args");
   const int64_t M = (int64_t)B * P;
   DISPATCH_G(G, hipLaunchKernelGGL(att_apply_bwd_rows_kernel<kG>, dim3(grid_for(M, 4)), dim3(256), 0, STREAM, dout,
                                    dout_ld, probs, vn, dscore, dvn, M, P, C));
   int rc = check_hip(hipGetLastError(), "att_apply_bwd_rows launch");
   if (rc) return rc;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(B * G), dim3(256), 0, STREAM, probs, dscore, P);
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(B * G), dim3(256), 0, STREAM, probs, dscore, P, dscore_rowsum);
   return check_hip(hipGetLastError(), "softmax_bwd launch");
 }
 

@@ -63,11 +63,12 @@ class Engine:
             raise ValueError("input images with more than 4 channels are not supported")
 
     def _side_streams(self, dev):
-        # VQA_STREAMS: 0 = one stream; 1 (default) = the two LSTM directions on two side streams, joined before
-        # the image branch; 2 = additionally under the convolutions.  Same box, interleaved, ms/step:
-        # 32.75 / 32.24 / 32.76 — the small M = 256 step GEMMs each fill half the chip, so pairing them helps,
-        # while the conv kernels already saturate it.
-        mode = os.environ.get("VQA_STREAMS", "1")
+        # VQA_STREAMS: 0 = one stream; 1 = the question branch on a side stream, joined before the image branch;
+        # 2 (default) = the question branch runs UNDER the convolutions (forward: joined before the attention stage,
+        # backward: joined at the end).  Same box, interleaved, B=256: 27.33 / 26.99 ms per step for 1 / 2 -- the
+        # LSTM step launches leave bubbles (prologue / cell epilogue / launch seams of a 44 us kernel) that
+        # convolution workgroups fill.
+        mode = os.environ.get("VQA_STREAMS", "2")
         if mode == "0":
             cur = torch.cuda.current_stream(dev)
             return [cur, cur]
@@ -132,51 +133,52 @@ class Engine:
         x_emb = ops.embed_tanh_fwd(q, P["text.embedding.weight"], p_txt, sd(SITE_TEXT), bad_tokens)       # [T,B,E]
         combined = new(B, Dc)
         lstm = [None] * self.ndir
+        fused = ops.lstm_step_supported(H) and os.environ.get("VQA_FUSED_LSTM", "1") == "1"
+        use_graph = os.environ.get("VQA_GRAPH", "1") == "1"
 
-        def run_direction(d):
-            sfx = "_reverse" if d else ""
-            w_ih, w_hh = P["text.lstm.weight_ih_l0" + sfx], P["text.lstm.weight_hh_l0" + sfx]
-            xg = new(T * B, 4 * H)
-            ops.gemm(x_emb, w_ih, xg, T * B, 4 * H, E, bias1=P["text.lstm.bias_ih_l0" + sfx],
-                     bias2=P["text.lstm.bias_hh_l0" + sfx], tag=10)
-            Hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=dev)
-            Cs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=dev)
-            gates = new(T, B, 4 * H)
-            fused = ops.lstm_step_supported(H) and os.environ.get("VQA_FUSED_LSTM", "1") == "1"
-            hg = None if fused else new(B, 4 * H)
-            order = range(T) if d == 0 else range(T - 1, -1, -1)
-            for n, t in enumerate(order):
-                si, so = (t, t + 1) if d == 0 else (t + 1, t)
-                last = n == T - 1
-                cf = combined[:, GC + d * H:] if last else None
-                if fused:   # recurrent GEMM with the cell as its epilogue: one launch per step
-                    ops.lstm_step_fwd(Hs[si], w_hh, xg[t * B:(t + 1) * B], Cs[si], q_len, t, gates[t], Cs[so], Hs[so],
-                                      cf, Dc)
-                else:
-                    ops.gemm(Hs[si], w_hh, hg, B, 4 * H, H, tag=11)
-                    ops.lstm_cell_fwd(xg[t * B:(t + 1) * B], hg, Cs[si], Hs[si], q_len, t, gates[t], Cs[so], Hs[so],
-                                      cf, Dc)
-            lstm[d] = SimpleNamespace(gates=gates, Hs=Hs, Cs=Cs, xg=xg, hg=hg)
+        def sfx(d):
+            return "_reverse" if d else ""
+
+        def run_question_branch():
+            for d in range(self.ndir):
+                xg = new(T * B, 4 * H)
+                ops.gemm(x_emb, P["text.lstm.weight_ih_l0" + sfx(d)], xg, T * B, 4 * H, E,
+                         bias1=P["text.lstm.bias_ih_l0" + sfx(d)], bias2=P["text.lstm.bias_hh_l0" + sfx(d)], tag=10)
+                lstm[d] = SimpleNamespace(gates=new(T, B, 4 * H), xg=xg, Hs=new(T + 1, B, H), Cs=new(T + 1, B, H))
+                lstm[d].Hs[T if d else 0].zero_()         # h_0 = c_0 = 0: only the initial slot is read before
+                lstm[d].Cs[T if d else 0].zero_()         # it is written
+            if fused:
+                # the whole recurrence, both directions per launch, as ONE call (a cached hipGraph of T launches)
+                dirs = [dict(w_hh=P["text.lstm.weight_hh_l0" + sfx(d)], xg=lstm[d].xg, gates=lstm[d].gates,
+                             Hs=lstm[d].Hs, Cs=lstm[d].Cs, c_final=combined[:, GC + d * H:], reverse=bool(d))
+                        for d in range(self.ndir)]
+                ops.lstm_seq_fwd(dirs, q_len, B, T, H, cf_ld=Dc, use_graph=use_graph)
+                return
+            for d in range(self.ndir):          # H % 32 != 0: recurrent GEMM + cell kernel per step
+                st, w_hh = lstm[d], P["text.lstm.weight_hh_l0" + sfx(d)]
+                hg = new(B, 4 * H)
+                order = range(T) if d == 0 else range(T - 1, -1, -1)
+                for n, t in enumerate(order):
+                    si, so = (t, t + 1) if d == 0 else (t + 1, t)
+                    cf = combined[:, GC + d * H:] if n == T - 1 else None
+                    ops.gemm(st.Hs[si], w_hh, hg, B, 4 * H, H, tag=11)
+                    ops.lstm_cell_fwd(st.xg[t * B:(t + 1) * B], hg, st.Cs[si], st.Hs[si], q_len, t, st.gates[t],
+                                      st.Cs[so], st.Hs[so], cf, Dc)
 
         # The question branch is a chain of small (M = B) launches, independent of the image branch until the
-        # attention stage: each LSTM direction runs on its own side stream.  Default schedule (VQA_STREAMS=1): the
-        # two directions overlap EACH OTHER and the main stream waits for both before the convolutions start;
-        # VQA_STREAMS=2 lets them run under the convolutions as well (measured no gain: the convs fill the chip).
+        # attention stage; it runs on a side stream, under the convolutions (VQA_STREAMS=2, the default; 1: the main
+        # stream waits for it before the convolutions start; 0: everything on one stream).
         main = torch.cuda.current_stream(dev)
         sides = self._side_streams(dev)
         fork = torch.cuda.Event()
         fork.record(main)
-        text_done = []
-        for d in range(self.ndir):
-            sides[d].wait_event(fork)
-            with torch.cuda.stream(sides[d]):
-                run_direction(d)
-                ev = torch.cuda.Event()
-                ev.record(sides[d])
-                text_done.append(ev)
-        if os.environ.get("VQA_STREAMS", "1") == "1":     # directions concurrent with each other only
-            for ev in text_done:
-                main.wait_event(ev)
+        sides[0].wait_event(fork)
+        with torch.cuda.stream(sides[0]):
+            run_question_branch()
+            text_done = torch.cuda.Event()
+            text_done.record(sides[0])
+        if os.environ.get("VQA_STREAMS", "2") == "1":
+            main.wait_event(text_done)
         # ---- image encoder: conv+relu+pool x L (models/model.py:79-84)
         # the first block has a dedicated kernel that reads the NCHW image as is (K = 27 is too thin for the
         # generic implicit GEMM); otherwise the image is converted to NHWC4 once
@@ -202,8 +204,7 @@ class Engine:
         # ---- image dropout + L2 normalisation over channels (model.py:84,56)
         p_img = self.p_image if tr else 0.0
         vn, norm = ops.l2norm_fwd(pooled, p_img, sd(SITE_IMAGE))
-        for ev in text_done:
-            main.wait_event(ev)
+        main.wait_event(text_done)
 
         qf = combined[:, GC:]
 
@@ -292,8 +293,9 @@ class Engine:
         ready("classifier")
 
         # ---- attention apply + scores
-        dscore, dvn = ops.att_apply_bwd(dcomb, Dc, ctx.probs, ctx.vn)
-        ops.sum_bgp(dscore, Gr["attention.x_conv.bias"])
+        ds_rows = new(B, G, 1)
+        dscore, dvn = ops.att_apply_bwd(dcomb, Dc, ctx.probs, ctx.vn, rowsum=ds_rows)
+        ops.sum_bgp(ds_rows, Gr["attention.x_conv.bias"])       # x_conv bias gradient: sum over samples of the row sums
         wx = P["attention.x_conv.weight"].view(G, -1)
         dwx_part, dq_part, RS = ops.att_score_bwd(dscore, wx, ctx.xs, B, Pn, ctx.p_att, sd(SITE_ATT_X),
                                                   mode=self.att_mode, vprime=ctx.vprime, qp=ctx.qp)
@@ -326,59 +328,74 @@ class Engine:
 
         # ---- LSTM (BPTT over the masked steps), embedding
         dx_parts = [new(T * B, E) for _ in range(self.ndir)]
+        fused = ops.lstm_step_supported(H) and os.environ.get("VQA_FUSED_LSTM", "1") == "1"
+        use_graph = os.environ.get("VQA_GRAPH", "1") == "1"
 
-        def bptt(d):
-            sfx = "_reverse" if d else ""
+        def sfx(d):
+            return "_reverse" if d else ""
+
+        def bptt_recurrence():
+            """dgates [T][B][4H] of every direction."""
+            dcs, dhs = [], []
+            for d in range(self.ndir):
+                dc = new(B, H)
+                ops.add2d(dcomb[:, GC + d * H:], Dc, None, 0, dc, H, B, H)
+                dcs.append(dc)
+                dhs.append(torch.zeros(B, H, dtype=torch.float32, device=dev))
+                ctx.lstm[d].dgates = new(T, B, 4 * H)          # kept alive until the streams have joined
+            if fused:
+                # one call: the first cell backward + T-1 fused (dgates . W_hh -> next cell backward) launches,
+                # every direction per launch, replayed as a cached hipGraph
+                dirs = [dict(w_hh=P["text.lstm.weight_hh_l0" + sfx(d)], gates=ctx.lstm[d].gates, Hs=ctx.lstm[d].Hs,
+                             Cs=ctx.lstm[d].Cs, dgates=ctx.lstm[d].dgates, dh=dhs[d], dc=dcs[d], reverse=bool(d))
+                        for d in range(self.ndir)]
+                ops.lstm_seq_bwd(dirs, ctx.q_len, B, T, H, use_graph=use_graph)
+                return
+            for d in range(self.ndir):
+                st, w_hh = ctx.lstm[d], P["text.lstm.weight_hh_l0" + sfx(d)]
+                order = range(T - 1, -1, -1) if d == 0 else range(T)
+                for n, t in enumerate(order):
+                    si, so = (t, t + 1) if d == 0 else (t + 1, t)
+                    ops.lstm_cell_bwd(st.gates[t], st.Cs[si], st.Cs[so], ctx.q_len, t, dhs[d], dcs[d], st.dgates[t])
+                    if n != T - 1:
+                        ops.gemm(st.dgates[t], w_hh, dhs[d], B, H, 4 * H, transB=False, lda=4 * H, ldb=H,
+                                 accumulate=True, tag=50)
+
+        def weight_grads(d):
             st = ctx.lstm[d]
-            w_ih, w_hh = P["text.lstm.weight_ih_l0" + sfx], P["text.lstm.weight_hh_l0" + sfx]
-            dc = new(B, H)
-            ops.add2d(dcomb[:, GC + d * H:], Dc, None, 0, dc, H, B, H)
-            dh = torch.zeros(B, H, dtype=torch.float32, device=dev)
-            dgates = new(T, B, 4 * H)
-            order = range(T - 1, -1, -1) if d == 0 else range(T)
-            for n, t in enumerate(order):
-                si, so = (t, t + 1) if d == 0 else (t + 1, t)
-                ops.lstm_cell_bwd(st.gates[t], st.Cs[si], st.Cs[so], ctx.q_len, t, dh, dc, dgates[t])
-                if n != T - 1:
-                    ops.gemm(dgates[t], w_hh, dh, B, H, 4 * H, transB=False, lda=4 * H, ldb=H, accumulate=True, tag=50)
+            dgates = st.dgates
             h_in = st.Hs[0:T] if d == 0 else st.Hs[1:T + 1]
-            ops.gemm(dgates, h_in, Gr["text.lstm.weight_hh_l0" + sfx], 4 * H, H, T * B, transA=True, transB=False,
+            ops.gemm(dgates, h_in, Gr["text.lstm.weight_hh_l0" + sfx(d)], 4 * H, H, T * B, transA=True, transB=False,
                      lda=4 * H, ldb=H, tag=51)
-            ops.gemm(dgates, ctx.x_emb, Gr["text.lstm.weight_ih_l0" + sfx], 4 * H, E, T * B, transA=True, transB=False,
-                     lda=4 * H, ldb=E, tag=52)
-            ops.colsum(dgates, T * B, 4 * H, Gr["text.lstm.bias_ih_l0" + sfx])
-            ops.add2d(Gr["text.lstm.bias_ih_l0" + sfx], 4 * H, None, 0, Gr["text.lstm.bias_hh_l0" + sfx], 4 * H, 1, 4 * H)
-            ops.gemm(dgates, w_ih, dx_parts[d], T * B, E, 4 * H, transB=False, lda=4 * H, ldb=E, tag=53)
-            st.dgates = dgates          # keep alive until the streams have joined
+            ops.gemm(dgates, ctx.x_emb, Gr["text.lstm.weight_ih_l0" + sfx(d)], 4 * H, E, T * B, transA=True,
+                     transB=False, lda=4 * H, ldb=E, tag=52)
+            ops.colsum(dgates, T * B, 4 * H, Gr["text.lstm.bias_ih_l0" + sfx(d)])
+            ops.add2d(Gr["text.lstm.bias_ih_l0" + sfx(d)], 4 * H, None, 0, Gr["text.lstm.bias_hh_l0" + sfx(d)], 4 * H, 1, 4 * H)
+            ops.gemm(dgates, P["text.lstm.weight_ih_l0" + sfx(d)], dx_parts[d], T * B, E, 4 * H, transB=False,
+                     lda=4 * H, ldb=E, tag=53)
 
-        # BPTT of each direction on its own side stream; direction 0's stream finishes the question branch (joins
-        # direction 1, embedding gradient) and hands the 'text' bucket to the data-parallel hook from there.  In the
-        # default schedule (VQA_STREAMS=1) the main stream waits for the question branch before the convolution
-        # backward, so only the 'text' all-reduce (not BPTT) overlaps the convolutions; VQA_STREAMS=2 drops that wait.
+        # The question branch's backward runs on a side stream: BPTT, the weight gradients of every direction, the
+        # embedding gradient, and from there the 'text' bucket goes to the data-parallel hook, so its all-reduce
+        # overlaps the convolution backward.  Default schedule (VQA_STREAMS=2): the branch runs under the convolution
+        # backward and is joined at the end; VQA_STREAMS=1: the main stream waits for it before the convolutions.
         main = torch.cuda.current_stream(dev)
         sides = self._side_streams(dev)
         fork = torch.cuda.Event()
         fork.record(main)
-        ev1 = None
-        if self.ndir > 1:
-            sides[1].wait_event(fork)
-            with torch.cuda.stream(sides[1]):
-                bptt(1)
-                ev1 = torch.cuda.Event()
-                ev1.record(sides[1])
         sides[0].wait_event(fork)
         with torch.cuda.stream(sides[0]):
-            bptt(0)
+            bptt_recurrence()
+            for d in range(self.ndir):
+                weight_grads(d)
             dx_emb = dx_parts[0]
-            if ev1 is not None:
-                sides[0].wait_event(ev1)
+            if self.ndir > 1:
                 ops.add(dx_parts[0], dx_parts[1], dx_emb)
             demb = Gr["text.embedding.weight"]       # every row is written (deterministic per-row sums)
             ops.embed_tanh_bwd(ctx.q, ctx.x_emb, dx_emb, demb, ctx.p_txt, sd(SITE_TEXT))
             ready("text")
             ev0 = torch.cuda.Event()
             ev0.record(sides[0])
-        if os.environ.get("VQA_STREAMS", "1") == "1":
+        if os.environ.get("VQA_STREAMS", "2") == "1":
             main.wait_event(ev0)
 
         # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first

@@ -168,11 +168,39 @@ def lstm_step_supported(H: int) -> bool:
     return bool(_lib.load().vqa_lstm_step_supported(H))
 
 
-def lstm_step_fwd(h_in, w_hh, xg_t, c_in, q_len, t, gates, c_out, h_out, c_final=None, cf_ld=0):
-    """One fused recurrent step: h_in @ w_hh.T on the MFMA engine + the LSTM cell as its epilogue."""
-    B, H = c_in.shape
-    call("vqa_lstm_step_fwd", ptr(h_in), ptr(w_hh), ptr(xg_t), ptr(c_in), ptr(q_len), t, ptr(gates), ptr(c_out),
-         ptr(h_out), ptr(c_final), cf_ld, B, H, stream())
+def _lstm_dirs(dirs):
+    """[{w_hh, xg, gates, Hs, Cs, c_final, dgates, dh, dc, reverse}] -> ctypes array of vqa_lstm_dir_t."""
+    arr = (_lib.LstmDir * len(dirs))()
+    for k, d in enumerate(dirs):
+        for f in ("w_hh", "xg", "gates", "Hs", "Cs", "c_final", "dgates", "dh", "dc"):
+            setattr(arr[k], f, ptr(d.get(f)))
+        arr[k].reverse = int(bool(d.get("reverse", False)))
+    return arr
+
+
+def lstm_seq_fwd(dirs, q_len, B: int, T: int, H: int, cf_ld: int = 0, use_graph: bool = True):
+    """The whole recurrence, forward: one call = T launches (each covers every direction), optionally as a cached
+    hipGraph.  dirs: list of dicts with tensors w_hh [4H,H], xg [T,B,4H], gates [T,B,4H], Hs / Cs [T+1,B,H]
+    (initial slot zeroed by the caller), optional c_final [B, cf_ld], reverse."""
+    import ctypes
+    arr = _lstm_dirs(dirs)
+    call("vqa_lstm_seq_fwd", ctypes.addressof(arr), len(dirs), ptr(q_len), B, T, H, cf_ld, int(use_graph), stream())
+
+
+def lstm_seq_bwd(dirs, q_len, B: int, T: int, H: int, use_graph: bool = True):
+    """BPTT of the recurrence: fills dgates [T,B,4H] per direction; dh (zeros) / dc (d loss / d c_n) are updated in
+    place.  Needs gates, Hs, Cs of the forward pass and w_hh."""
+    import ctypes
+    arr = _lstm_dirs(dirs)
+    call("vqa_lstm_seq_bwd", ctypes.addressof(arr), len(dirs), ptr(q_len), B, T, H, int(use_graph), stream())
+
+
+def lstm_graph_stats():
+    """(replays, builds, plain-launch fallbacks, cached graphs) of the library's LSTM-sequence hipGraph cache."""
+    import ctypes
+    a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    n = _lib.load().vqa_lstm_graph_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    return a.value, b.value, c.value, n
 
 
 def lstm_cell_bwd(gates, c_in, c_out, q_len, t, dh, dc, dgates):
@@ -210,12 +238,14 @@ def att_apply_fwd(score, vn, out, out_ld):
     return probs
 
 
-def att_apply_bwd(dout, dout_ld, probs, vn, dvn_out=None):
+def att_apply_bwd(dout, dout_ld, probs, vn, dvn_out=None, rowsum=None):
+    """rowsum: optional [B, G] output, sum over positions of dscore (per-sample x_conv bias gradient)."""
     B, G, P = probs.shape
     C = vn.shape[-1]
     dscore = torch.empty_like(probs)
     dvn = dvn_out if dvn_out is not None else torch.empty_like(vn)
-    call("vqa_att_apply_bwd", ptr(dout), dout_ld, ptr(probs), ptr(vn), ptr(dscore), ptr(dvn), B, P, C, G, stream())
+    call("vqa_att_apply_bwd", ptr(dout), dout_ld, ptr(probs), ptr(vn), ptr(dscore), ptr(dvn), ptr(rowsum), B, P, C, G,
+         stream())
     return dscore, dvn
 
 

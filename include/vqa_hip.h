@@ -10,8 +10,8 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it;
  *   - return value: 0 = success, otherwise a VQA_ERR_* code; vqa_last_error() gives the text;
  *   - no C++ exception crosses the ABI; functions are re-entrant (safe from any host thread, any device);
- *     the only state is the optional profiling hook, the VQA_* knobs (read once) and a per-device record of
- *     kernels whose LDS limit has been raised, all behind mutexes;
+ *     the only state is the optional profiling hook, the VQA_* knobs (read once), a per-device record of
+ *     kernels whose LDS limit has been raised and the cache of LSTM-sequence hipGraphs, all behind mutexes;
  *   - all floating point is IEEE fp32; contractions use v_mfma_f32_32x32x2_f32 (exact fp32);
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS; pointers and leading
  *     dimensions of GEMM operands must be multiples of 4 elements (16-byte vector loads);
@@ -146,15 +146,36 @@ int vqa_lstm_cell_fwd(const float* xg, const float* hg, const float* c_in, const
 int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out, const int64_t* q_len,
                       int t, float* dh, float* dc, float* dgates, int B, int H, vqa_stream_t stream);
 
-/* Fused recurrent step (models/model.py:145-149, 159-164): h_in W_hh^T on the MFMA engine with the cell as its
- * epilogue -- replaces vqa_gemm(h_in, w_hh -> hg) + vqa_lstm_cell_fwd for one time step and direction.
- *   h_in [B][H], w_hh [4H][H] (PyTorch gate order i,f,g,o), xg_t [B][4H] = x_t W_ih^T + b_ih + b_hh,
- *   c_in [B][H], q_len [B] int64 (sample b advances only while t < q_len[b]); outputs as vqa_lstm_cell_fwd.
- * Requires H % 32 == 0 (vqa_lstm_step_supported); other sizes use the unfused pair. */
+/* The whole recurrence of one question batch as ONE call (models/model.py:145-149, 159-164): T dependent launches,
+ * each covering every direction; a forward step is h_{t-1} W_hh^T on the MFMA engine with the cell as its epilogue,
+ * a backward step is dgates_t W_hh over the whole K = 4H inside one workgroup (split over its MFMA waves by gate,
+ * combined through LDS) with the cell backward of the next time as its epilogue -- they replace vqa_gemm +
+ * vqa_lstm_cell_fwd, resp. vqa_lstm_cell_bwd + split-K vqa_gemm + reduce, per step and direction.
+ * Requires H % 32 == 0 (vqa_lstm_step_supported); other sizes use the unfused entry points above.
+ *   use_graph != 0: the chain is replayed as an explicit hipGraph, built once per distinct argument set (shapes AND
+ *   pointers) and cached inside the library (at most 32 graphs per process, least recently used dropped; a caller
+ *   whose buffers move on every call is detected and served by plain launches).  vqa_lstm_graph_stats reports
+ *   replays / graph builds / plain-launch fallbacks since load and returns the number of cached graphs.
+ * Layouts: time-major.  The forward direction reads state slot t and writes slot t+1 of Hs / Cs [T+1][B][H] at time
+ * t, the reverse direction reads slot t+1 and writes slot t; the caller zeroes the initial slot (0, resp. T). */
+typedef struct {
+  const float* w_hh; /* [4H][H], PyTorch gate order i,f,g,o */
+  const float* xg;   /* fwd: [T][B][4H] = x_t W_ih^T + b_ih + b_hh (vqa_gemm) */
+  float* gates;      /* [T][B][4H] gate activations, zero rows where t >= q_len[b] (fwd: out, bwd: in) */
+  float* Hs;         /* [T+1][B][H] */
+  float* Cs;         /* [T+1][B][H] */
+  float* c_final;    /* fwd: optional [B][cf_ld], final cell state c_n (the question feature, model.py:164-166) */
+  float* dgates;     /* bwd: [T][B][4H] out: gradient w.r.t. the gate pre-activations */
+  float* dh;         /* bwd: [B][H] work; on entry d loss / d h_n (zeros for this model) */
+  float* dc;         /* bwd: [B][H] work; on entry d loss / d c_n, on exit d loss / d c at the first processed time */
+  int reverse;       /* 0: t = 0 .. T-1, 1: t = T-1 .. 0 */
+} vqa_lstm_dir_t;
 int vqa_lstm_step_supported(int H);
-int vqa_lstm_step_fwd(const float* h_in, const float* w_hh, const float* xg_t, const float* c_in,
-                      const int64_t* q_len, int t, float* gates, float* c_out, float* h_out, float* c_final,
-                      int64_t cf_ld, int B, int H, vqa_stream_t stream);
+int vqa_lstm_seq_fwd(const vqa_lstm_dir_t* dirs, int ndir, const int64_t* q_len, int B, int T, int H,
+                     int64_t cf_ld, int use_graph, vqa_stream_t stream);
+int vqa_lstm_seq_bwd(const vqa_lstm_dir_t* dirs, int ndir, const int64_t* q_len, int B, int T, int H,
+                     int use_graph, vqa_stream_t stream);
+int vqa_lstm_graph_stats(int* replays, int* builds, int* plain);
 
 /* ---- attention (models/model.py:169-195 Attention, 208-221 image_question_attention) ---------
  * x = relu(v' (+|*) q') comes from vqa_gemm(rowgroup = q') as xs[m][n]; for do_option '|' (model.py:192)
@@ -175,9 +196,11 @@ int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, float* xs
 /* probs = softmax_p(score); out[b*out_ld + g*C + c] = sum_p probs[b][g][p] * vn[b][p][c] */
 int vqa_att_apply_fwd(const float* score, const float* vn, float* probs, float* out, int64_t out_ld,
                       int B, int P, int C, int G, vqa_stream_t stream);
-/* dscore[b][g][p] and dvn[b][p][c] (written) from dout[b*dout_ld + g*C + c]. */
+/* dscore[b][g][p] and dvn[b][p][c] (written) from dout[b*dout_ld + g*C + c]; dscore_rowsum (optional)
+ * [b][g] = sum_p dscore[b][g][p], the per-sample part of the x_conv bias gradient. */
 int vqa_att_apply_bwd(const float* dout, int64_t dout_ld, const float* probs, const float* vn,
-                      float* dscore, float* dvn, int B, int P, int C, int G, vqa_stream_t stream);
+                      float* dscore, float* dvn, float* dscore_rowsum, int B, int P, int C, int G,
+                      vqa_stream_t stream);
 
 /* ---- loss head (train.py:190-207, utils/train_utils.py:12-25) -------------------------------
  * loss_rows[b] = sum_k -log_softmax(logits[b])[a_idx[b][k]-1] * a_val[b][k]/10 * inv_batch

@@ -326,40 +326,119 @@ def test_lstm_cell_fwd_bwd():
     check("lstm cell dh passthrough", dhd, hr.grad, 5e-6)
 
 
-@pytest.mark.parametrize("B,H,t", [(6, 32, 2), (70, 64, 0), (256, 1024, 5), (130, 96, 3)])
-def test_lstm_fused_step_matches_gemm_plus_cell(B, H, t):
-    """vqa_lstm_step_fwd (recurrent GEMM with the cell as its epilogue) against fp64 math and, bit for bit on the
-    states, against the unfused pair vqa_gemm + vqa_lstm_cell_fwd it replaces."""
+def _lstm_reference(xg, w_hh, q_len, reverse, dcn):
+    """fp64 masked LSTM recurrence of one direction (the oracle's loop) with autograd: returns the saved gate
+    activations [T,B,4H] (zero rows where inactive), the state chains in the library's slot convention, c_n, and the
+    gradients w.r.t. the gate pre-activations [T,B,4H] for d loss / d c_n = dcn."""
+    T, B, H4 = xg.shape
+    H = H4 // 4
+    w = w_hh.double()
+    pres = [None] * T
+    h = torch.zeros(B, H, dtype=torch.float64)
+    c = torch.zeros(B, H, dtype=torch.float64)
+    Hs, Cs = torch.zeros(T + 1, B, H, dtype=torch.float64), torch.zeros(T + 1, B, H, dtype=torch.float64)
+    gates = torch.zeros(T, B, 4 * H, dtype=torch.float64)
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        x_t = xg[t].double().clone().requires_grad_(True)
+        pres[t] = x_t
+        pre = x_t + h @ w.t()
+        i, f, g, o = pre.split(H, dim=1)
+        i, f, o, g = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o), torch.tanh(g)
+        cn = f * c + i * g
+        hn = o * torch.tanh(cn)
+        m = (q_len > t).double().unsqueeze(1)
+        gates[t] = (m * torch.cat([i, f, g, o], dim=1)).detach()
+        c = m * cn + (1 - m) * c
+        h = m * hn + (1 - m) * h
+        so = t if reverse else t + 1
+        Hs[so], Cs[so] = h.detach(), c.detach()
+    (c * dcn.double()).sum().backward()
+    dg = torch.stack([p.grad if p.grad is not None else torch.zeros(B, 4 * H, dtype=torch.float64) for p in pres])
+    return gates, Hs, Cs, c.detach(), dg
+
+
+@pytest.mark.parametrize("B,H,T,ndir", [(6, 32, 4, 2), (70, 64, 5, 2), (130, 96, 3, 1), (256, 1024, 3, 2), (3, 32, 1, 2)])
+@pytest.mark.parametrize("graph", [False, True])
+def test_lstm_sequence_fwd_bwd(B, H, T, ndir, graph):
+    """vqa_lstm_seq_fwd / vqa_lstm_seq_bwd (one call per sequence, every direction per launch, plain launches or a
+    cached hipGraph) against an fp64 masked recurrence with autograd: saved gates, state chains, c_n written into a
+    strided output, and the gate pre-activation gradients of BPTT; ragged lengths incl. 1 and T."""
     ops = _ops()
     assert ops.lstm_step_supported(H) and not ops.lstm_step_supported(20)
-    g = torch.Generator().manual_seed(B + H)
-    q_len = torch.randint(1, 8, (B,), generator=g)
-    w_hh = torch.randn(4 * H, H, generator=g) / math.sqrt(H)
-    xg = torch.randn(B, 4 * H, generator=g)
-    c0, h0 = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
-    pre = xg.double() + h0.double() @ w_hh.double().t()
-    i, f, gg, o = pre.split(H, dim=1)
-    cn = torch.sigmoid(f) * c0.double() + torch.sigmoid(i) * torch.tanh(gg)
-    hn = torch.sigmoid(o) * torch.tanh(cn)
-    m = (q_len > t).double().unsqueeze(1)
-    c1, h1 = m * cn + (1 - m) * c0.double(), m * hn + (1 - m) * h0.double()
-    gref = m * torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)], dim=1)
-
+    g = torch.Generator().manual_seed(B + H + T)
+    q_len = torch.randint(1, T + 1, (B,), generator=g)
+    q_len[0], q_len[-1] = T, 1
     d = lambda x: x.to(DEV)
-    new = lambda *s_: torch.full(s_, 9.0, device=DEV)
-    gates, c_out, h_out, cf = new(B, 4 * H), new(B, H), new(B, H), torch.zeros(B, 2 * H + 4, device=DEV)
-    ops.lstm_step_fwd(d(h0), d(w_hh), d(xg), d(c0), d(q_len), t, gates, c_out, h_out, cf[:, 4:], 2 * H + 4)
-    hg, gates2, c2, h2 = new(B, 4 * H), new(B, 4 * H), new(B, H), new(B, H)
-    ops.gemm(d(h0), d(w_hh), hg, B, 4 * H, H)
-    ops.lstm_cell_fwd(d(xg), hg, d(c0), d(h0), d(q_len), t, gates2, c2, h2, None, 0)
+    dirs_f, dirs_b, refs, keep = [], [], [], []
+    cf = torch.zeros(B, ndir * H + 4, device=DEV)
+    for k in range(ndir):
+        w_hh = torch.randn(4 * H, H, generator=g) / math.sqrt(H)
+        xg = torch.randn(T, B, 4 * H, generator=g)
+        dcn = torch.randn(B, H, generator=g)
+        refs.append(_lstm_reference(xg, w_hh, q_len, bool(k), dcn))
+        t_ = dict(w_hh=d(w_hh), xg=d(xg), gates=torch.full((T, B, 4 * H), 9.0, device=DEV),
+                  Hs=torch.full((T + 1, B, H), 9.0, device=DEV), Cs=torch.full((T + 1, B, H), 9.0, device=DEV),
+                  c_final=cf[:, 4 + k * H:], reverse=bool(k))
+        t_["Hs"][T if k else 0].zero_()
+        t_["Cs"][T if k else 0].zero_()
+        dirs_f.append(t_)
+        dirs_b.append(dict(w_hh=t_["w_hh"], gates=t_["gates"], Hs=t_["Hs"], Cs=t_["Cs"],
+                           dgates=torch.full((T, B, 4 * H), 9.0, device=DEV), dh=torch.zeros(B, H, device=DEV),
+                           dc=d(dcn.clone()), reverse=bool(k)))
+        keep.append(dcn)
+    ql = d(q_len)
+    before = ops.lstm_graph_stats()
+    for rep in range(2):                       # the second round replays the cached graphs (same buffers)
+        for k in range(ndir):
+            dirs_b[k]["dh"].zero_()
+            dirs_b[k]["dc"].copy_(keep[k])
+        ops.lstm_seq_fwd(dirs_f, ql, B, T, H, cf_ld=ndir * H + 4, use_graph=graph)
+        ops.lstm_seq_bwd(dirs_b, ql, B, T, H, use_graph=graph)
     torch.cuda.synchronize()
-    check("fused lstm c", c_out, c1, 5e-6)
-    check("fused lstm h", h_out, h1, 5e-6)
-    check("fused lstm gates", gates, gref, 5e-6)
-    check("fused lstm c_final", cf[:, 4:4 + H], c1, 5e-6)
-    assert float(cf[:, :4].abs().max()) == 0.0 and float(cf[:, 4 + H:].abs().max()) == 0.0
-    assert float((c_out - c2).abs().max()) < 2e-6 and float((h_out - h2).abs().max()) < 2e-6
-    assert float((gates - gates2).abs().max()) < 2e-6
+    after = ops.lstm_graph_stats()
+    if graph:
+        assert after[0] - before[0] >= 2 and after[1] - before[1] <= 2, (before, after)   # >= 2 replays, <= 2 builds
+    else:
+        assert after[:3] == before[:3]
+    assert float(cf[:, :4].abs().max()) == 0.0
+    for k in range(ndir):
+        gates, Hs, Cs, cn, dg = refs[k]
+        check(f"lstm seq gates dir{k}", dirs_f[k]["gates"], gates, 5e-6)
+        check(f"lstm seq Hs dir{k}", dirs_f[k]["Hs"], Hs, 5e-6)
+        check(f"lstm seq Cs dir{k}", dirs_f[k]["Cs"], Cs, 5e-6)
+        check(f"lstm seq c_n dir{k}", cf[:, 4 + k * H:4 + (k + 1) * H], cn, 5e-6)
+        check(f"lstm seq dgates dir{k}", dirs_b[k]["dgates"], dg, 2e-5)
+
+
+def test_lstm_sequence_matches_unfused_path():
+    """The fused sequence kernels against the unfused entry points they replace (vqa_gemm + vqa_lstm_cell_fwd, resp.
+    vqa_lstm_cell_bwd + vqa_gemm(accumulate)) at the bench shape B=256, H=1024."""
+    ops = _ops()
+    B, H, T = 256, 1024, 4
+    g = torch.Generator().manual_seed(3)
+    q_len = torch.randint(1, T + 1, (B,), generator=g).to(DEV)
+    w_hh = (torch.randn(4 * H, H, generator=g) / math.sqrt(H)).to(DEV)
+    xg = torch.randn(T, B, 4 * H, generator=g).to(DEV)
+    dcn = torch.randn(B, H, generator=g).to(DEV)
+    z = lambda *s_: torch.zeros(*s_, device=DEV)
+    f = dict(w_hh=w_hh, xg=xg, gates=z(T, B, 4 * H), Hs=z(T + 1, B, H), Cs=z(T + 1, B, H), c_final=None, reverse=False)
+    ops.lstm_seq_fwd([f], q_len, B, T, H, use_graph=False)
+    b = dict(w_hh=w_hh, gates=f["gates"], Hs=f["Hs"], Cs=f["Cs"], dgates=z(T, B, 4 * H), dh=z(B, H), dc=dcn.clone())
+    ops.lstm_seq_bwd([b], q_len, B, T, H, use_graph=False)
+    gates, Hs, Cs, hg = z(T, B, 4 * H), z(T + 1, B, H), z(T + 1, B, H), z(B, 4 * H)
+    for t in range(T):
+        ops.gemm(Hs[t], w_hh, hg, B, 4 * H, H)
+        ops.lstm_cell_fwd(xg[t], hg, Cs[t], Hs[t], q_len, t, gates[t], Cs[t + 1], Hs[t + 1], None, 0)
+    dg, dh, dc = z(T, B, 4 * H), z(B, H), dcn.clone()
+    for t in range(T - 1, -1, -1):
+        ops.lstm_cell_bwd(gates[t], Cs[t], Cs[t + 1], q_len, t, dh, dc, dg[t])
+        if t:
+            ops.gemm(dg[t], w_hh, dh, B, H, 4 * H, transB=False, lda=4 * H, ldb=H, accumulate=True)
+    torch.cuda.synchronize()
+    check("seq vs unfused gates", f["gates"], gates.double(), 2e-6)
+    check("seq vs unfused Cs", f["Cs"], Cs.double(), 2e-6)
+    check("seq vs unfused dgates", b["dgates"], dg.double(), 2e-5)
+    check("seq vs unfused dc", b["dc"], dc.double(), 2e-5)
 
 
 def test_attention_score_and_apply():

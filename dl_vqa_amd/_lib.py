@@ -34,7 +34,7 @@ PROTOTYPES = {
     "vqa_conv3x3_wgrad": (i32, [f32p, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32,
                                 f32p, i64, i32, vp]),
     "vqa_conv0_supported": (i32, [i32, i32, i32, i32, i32]),
-    "vqa_conv0_relu_pool_fwd": (i32, [f32p, f32p, f32p, f32p, u8p, i32, i32, i32, i32, i32, vp]),
+    "vqa_conv0_relu_pool_fwd": (i32, [f32p, f32p, f32p, vp, i32, u8p, i32, i32, i32, i32, i32, vp]),
     "vqa_conv0_wgrad_workspace_bytes": (i64, [i32]),
     "vqa_conv0_wgrad": (i32, [f32p, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, vp]),
     "vqa_dropout": (i32, [f32p, f32p, i64, f32, u64, vp]),
@@ -62,6 +62,18 @@ PROTOTYPES = {
     "vqa_add2d": (i32, [f32p, i64, f32p, i64, f32p, i64, i64, i32, vp]),
     "vqa_scale_by": (i32, [f32p, i64, f32p, vp]),
     "vqa_half_to_float": (i32, [vp, f32p, i64, vp]),
+    "vqa_f32_to_bf16": (i32, [f32p, vp, i64, vp]),
+    "vqa_bf16_to_f32": (i32, [vp, f32p, i64, vp]),
+    "vqa_dropout_to_bf16": (i32, [f32p, vp, i64, f32, u64, vp]),
+    "vqa_f32_to_bf16_transpose": (i32, [f32p, vp, i32, i32, vp]),
+    "vqa_gemm_bf16_workspace_bytes": (i64, [i32, i32, i32]),
+    "vqa_gemm_bf16": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, i32, i32, i32, f32p, f32p,
+                            f32p, i64, i32, i32, i32, i32, f32p, f32p, i64, i32, vp]),
+    "vqa_conv_pack_weights_bf16": (i32, [f32p, vp, vp, i32, i32, i32, vp]),
+    "vqa_conv3x3_relu_pool_fwd_bf16": (i32, [vp, vp, f32p, vp, i32, u8p, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "vqa_conv3x3_dgrad_bf16": (i32, [vp, u8p, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "vqa_conv3x3_wgrad_bf16_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
+    "vqa_conv3x3_wgrad_bf16": (i32, [vp, vp, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, f32p, i64, i32, vp]),
     "vqa_adam": (i32, [f32p, f32p, f32p, f32p, i64, f32, f32, f32, f32, i32, f32, vp]),
 }
 

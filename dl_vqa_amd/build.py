@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvqa_hip.so")
-SOURCES = ["gemm.hip", "conv.hip", "conv0.hip", "lstm.hip", "elementwise.hip"]
-HEADERS = ["common.hpp", "gemm_core.hpp", "conv_device.inc", os.path.join("..", "..", "include", "vqa_hip.h")]
+SOURCES = ["gemm.hip", "conv.hip", "conv0.hip", "lstm.hip", "elementwise.hip", "bf16.hip", "conv_bf16.hip"]
+HEADERS = ["common.hpp", "gemm_core.hpp", "gemm_epilogue.hpp", "bf16_core.hpp", "conv_device.inc", "conv_host.inc", "conv_bf16.inc", os.path.join("..", "..", "include", "vqa_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 
@@ -51,7 +51,7 @@ def build_library(force: bool = False, verbose: bool = True, diag: bool = False)
             raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
         return r
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)

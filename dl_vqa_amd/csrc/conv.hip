@@ -13,7 +13,7 @@
 //           pooled gradient and the stored arg-max byte (one non-zero per 2x2 window).
 // wgrad     out[(ky,kx,ci)][co] = sum over conv-output pixels; split along that (huge) reduction over
 //           workgroups into slabs, then reduced and transposed to the torch layout [Co][Ci][3][3].
-#include "gemm_core.hpp"
+#include "bf16_core.hpp"
 
 namespace vqa {
 
@@ -22,6 +22,7 @@ int colsum_launch(const float* x, int64_t ld, const uint8_t* mask, int64_t rows,
 int64_t colsum_ws_bytes(int64_t rows, int cols);
 
 #include "conv_device.inc"
+#include "conv_host.inc"
 
 using Cfg128 = TileCfg<128, 128, 2, 2>;
 using Cfg128x64 = TileCfg<128, 64, 2, 2>;
@@ -54,11 +55,6 @@ using Cfg256x64L8 = TileCfg<256, 64, 4, 2, 8>;
 // dgrad with CiP <= 64 (conv1): a K-step is only 32 MFMAs per wave, so the loaders are the long pole; with 8
 // loader waves (768 threads, 74 VGPRs: two workgroups = 6 waves per SIMD) 70.6 -> 73.0 % on the same box
 using Cfg128x64L8 = TileCfg<128, 64, 2, 2, 8, 2>;
-
-template <class K>
-static int set_smem(K kern, int bytes, const char* what) {
-  return ensure_dyn_smem(reinterpret_cast<const void*>(kern), bytes, what);
-}
 
 template <class Cfg, bool U>
 static int launch_fwd(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* amax,
@@ -159,37 +155,6 @@ static int launch_wgrad(const float* x, const float* dp, const uint8_t* am, floa
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, slab,
                      bias_slab, p.tiles_m, p.tiles_n, p.nk, p.ks_per_split);
   return check_hip(hipGetLastError(), "conv_wgrad launch");
-}
-
-static int check_geom(const char* fn, const ConvGeom& g) {
-  VQA_REQUIRE(g.B > 0 && g.H >= 3 && g.W >= 3, "%s: bad image shape B=%d H=%d W=%d", fn, g.B, g.H, g.W);
-  VQA_REQUIRE(g.CiP % 4 == 0 && g.Co % 4 == 0 && g.CiP > 0 && g.Co > 0,
-              "%s: channel counts must be positive multiples of 4 (CiP=%d Co=%d)", fn, g.CiP, g.Co);
-  VQA_REQUIRE(g.stride == 1 || g.stride == 2, "%s: stride %d unsupported (1 or 2)", fn, g.stride);
-  VQA_REQUIRE(g.Hp > 0 && g.Wp > 0, "%s: image too small for conv+pool", fn);
-  VQA_REQUIRE((int64_t)g.B * g.H * g.W < (1LL << 31) / 4, "%s: too many pixels for 32-bit row indices", fn);
-  // the loaders address each tensor with 32-bit byte offsets from its first element
-  VQA_REQUIRE((int64_t)g.B * g.H * g.W * g.CiP * 4 < 0xffff0000LL && (int64_t)g.B * g.Hp * g.Wp * g.Co * 4 < 0xffff0000LL,
-              "%s: a tensor of this launch reaches 4 GiB (B=%d)", fn, g.B);
-  return VQA_OK;
-}
-
-// The loaders address every tensor with 32-bit byte offsets, so a launch covers at most `chunk` images (all
-// tensors of the layer below 4 GiB, pixel rows below 2^29); the C ABI entry points walk larger batches in
-// chunks -- images are independent, wgrad's chunks are simply more split-K slabs for the same reduce.
-static int batch_chunk(int B, int H, int W, int CiP, int Co, int stride) {
-  const ConvGeom g = make_geom(1, H, W, CiP, Co, stride);
-  const int64_t in_b = (int64_t)H * W * CiP * 4, out_b = (int64_t)(g.Hp > 0 ? g.Hp : 1) * (g.Wp > 0 ? g.Wp : 1) * Co * 4;
-  const int64_t per_img = in_b > out_b ? in_b : out_b;
-  int64_t c = (0xffff0000LL - 1) / per_img;
-  const int64_t by_rows = ((1LL << 31) / 4 - 1) / ((int64_t)H * W);
-  if (by_rows < c) c = by_rows;
-  if (c > B) c = B;
-  {   // tests: force small chunks on small tensors (VQA_CONV_CHUNK)
-    const int64_t f = knobs().conv_chunk;
-    if (f > 0 && f < c) c = f;
-  }
-  return (int)c;     // 0: a single image is already too large
 }
 
 }  // namespace vqa

@@ -14,7 +14,7 @@
 //             loads); each wave keeps its 32 x Co partial dW in accumulators for its whole lifetime and
 //             writes ONE slab at the end (deterministic two-level reduction, no atomics).
 // LDS row strides are chosen per kernel so that the 32 lanes of a fragment read hit 32 different banks.
-#include "gemm_core.hpp"
+#include "bf16_core.hpp"
 
 namespace vqa {
 
@@ -35,10 +35,13 @@ __host__ __device__ inline int c0_round_stride(int W, int want_mod) {
 constexpr int C0_FR = 4;
 constexpr int C0_PR = 2 * C0_FR + 2;
 
-template <int CI, int TN>
+// OB: pooled is stored as bf16 (the bf16 path's P_0) instead of fp32
+template <int CI, int TN, bool OB>
 __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* pooled, uint8_t* amax,
+                                                        const float* __restrict__ bias, void* pooled_, uint8_t* amax,
                                                         int H, int W, int Hp, int Wp, int RS) {
+  float* pooled = static_cast<float*>(pooled_);
+  uint16_t* pooled16 = static_cast<uint16_t*>(pooled_);
   extern __shared__ __attribute__((aligned(16))) float patch[];
   constexpr int K = 9 * CI, NS = (K + 1) / 2, Co = 32 * TN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restri
   const int nwin = nwr * Wp, ntiles = (nwin + 7) / 8;
   // windows of the workgroup are consecutive in memory: offset = first window + wo * Co
   const int64_t o0 = (int64_t)(b * Hp + py0) * Wp * Co;
-  const __amdgpu_buffer_rsrc_t rp = buf_rsrc(pooled + o0), ra = buf_rsrc(amax + o0);
+  const __amdgpu_buffer_rsrc_t rp = OB ? buf_rsrc(pooled16 + o0) : buf_rsrc(pooled + o0), ra = buf_rsrc(amax + o0);
   for (int t = wave; t < ntiles; t += 4) {
     // A rows: row i = 4*window + pixel (the engine's window-in-4-registers layout)
     int wdx = 8 * t + (l31 >> 2);
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restri
         if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
         best += bv[j];
         const uint32_t so = (uint32_t)(2 * g * Co + 32 * j);
-        buf_store4(rp, best > 0.f ? best : 0.f, ok ? 4u * vl : BUF_OOB, 4u * so);
+        if (OB) buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl : BUF_OOB, 2u * so);
+        else buf_store4(rp, best > 0.f ? best : 0.f, ok ? 4u * vl : BUF_OOB, 4u * so);
         buf_store1(ra, best > 0.f ? (uint8_t)a : (uint8_t)4, ok ? vl : BUF_OOB, so);
       }
     }
@@ -253,16 +257,21 @@ extern "C" {
 
 int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride) { return c0_supported(Ci, H, W, Co, stride) ? 1 : 0; }
 
-int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, float* pooled, uint8_t* argmax,
-                            int B, int Ci, int H, int W, int Co, vqa_stream_t stream) {
+int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, void* pooled, int pooled_is_bf16,
+                            uint8_t* argmax, int B, int Ci, int H, int W, int Co, vqa_stream_t stream) {
   VQA_REQUIRE(x_nchw && w && bias && pooled && argmax && B > 0, "vqa_conv0_relu_pool_fwd: bad args");
   VQA_REQUIRE(c0_supported(Ci, H, W, Co, 1), "vqa_conv0_relu_pool_fwd: unsupported shape Ci=%d H=%d W=%d Co=%d", Ci, H, W, Co);
   VQA_REQUIRE(((uintptr_t)x_nchw % 16) == 0, "vqa_conv0_relu_pool_fwd: input must be 16-byte aligned");
   const int Hp = (H - 2) / 2, Wp = (W - 2) / 2, RS = c0_round_stride(W, 16);
   const size_t lds = (size_t)Ci * C0_PR * RS * 4;
   const dim3 grid((Hp + C0_FR - 1) / C0_FR, B);
-  C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_fwd_kernel<kCI, kTN>), grid, dim3(256), lds, (hipStream_t)stream,
-                                              x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS));
+  if (pooled_is_bf16) {
+    C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_fwd_kernel<kCI, kTN, true>), grid, dim3(256), lds, (hipStream_t)stream,
+                                                x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS));
+  } else {
+    C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_fwd_kernel<kCI, kTN, false>), grid, dim3(256), lds, (hipStream_t)stream,
+                                                x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS));
+  }
   return check_hip(hipGetLastError(), "conv0_fwd launch");
 }
 

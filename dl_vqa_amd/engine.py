@@ -27,7 +27,7 @@ def _site_seed(base: int, site: int) -> int:
 
 
 class Engine:
-    def __init__(self, cfg: dict, embedding_tokens: int):
+    def __init__(self, cfg: dict, embedding_tokens: int, compute_dtype: str = "fp32"):
         t, i, a, c = cfg["text"], cfg["image"], cfg["attention"], cfg["classifier"]
         self.V = embedding_tokens
         self.E = t["embedding_features"]
@@ -61,6 +61,16 @@ class Engine:
                 raise ValueError(f"{name}={val}: the HIP kernels need multiples of 4 (16-byte vector loads)")
         if self.channels[0] > 4:
             raise ValueError("input images with more than 4 channels are not supported")
+        # bf16 path (BASELINE configs[3]): conv blocks 1.. and the v_conv products on bf16 MFMA (fp32 accumulate),
+        # activations between the conv blocks stored as bf16; parameters, LSTM, reductions and the optimiser stay
+        # fp32.  Opt-in; fp32 is the parity path.
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"compute_dtype {compute_dtype!r} (fp32 or bf16)")
+        self.bf16 = compute_dtype == "bf16"
+        if self.bf16:
+            if self.L < 2 or any(ch % 64 for ch in self.channels[1:]) or self.mid % 8 or self.stride != 1:
+                raise ValueError("the bf16 path needs >= 2 conv blocks, stride 1 and channel counts that are multiples "
+                                 f"of 64 after the first block (num_channels={self.channels}, stride={self.stride})")
 
     def _side_streams(self, dev):
         # VQA_STREAMS: 0 = one stream; 1 = the question branch on a side stream, joined before the image branch;
@@ -189,10 +199,23 @@ class Engine:
             w = P[f"image.conv{l}.weight"]
             assert w.shape[0] == self.channels[l + 1]
             if l == 0 and fast0:
-                pooled, am = ops.conv0_fwd(v, w, P["image.conv0.bias"])
+                pooled, am = ops.conv0_fwd(v, w, P["image.conv0.bias"],
+                                           out_dtype=torch.bfloat16 if self.bf16 else torch.float32)
                 acts.append(pooled)
                 idxs.append(am)
                 wds.append(None)
+                continue
+            if self.bf16:
+                if l == 0:
+                    raise ValueError("the bf16 path needs the dedicated first-block kernel (3-channel NCHW image, "
+                                     "W % 4 == 0, 32 or 64 output channels)")
+                # bf16 activations in, bf16 out (fp32 out of the last block: the L2 normalisation consumes it)
+                wfT, wdT = ops.conv_pack_weights_bf16(w, acts[-1].shape[3], need_wd=keep)
+                pooled, am = ops.conv_fwd_bf16(acts[-1], wfT, P[f"image.conv{l}.bias"], self.stride,
+                                               out_dtype=torch.float32 if l == self.L - 1 else torch.bfloat16, tag=l)
+                acts.append(pooled)
+                idxs.append(am)
+                wds.append(wdT)
                 continue
             wf, wd = ops.conv_pack_weights(w, acts[-1].shape[3], need_wd=(keep and l > 0))
             pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l)
@@ -210,8 +233,12 @@ class Engine:
 
         # ---- attention (model.py:183-195): v' = v_conv(drop(v)), q' = q_lin(drop(q)), x = relu(v' + q')
         p_att = self.p_att if tr else 0.0
+        v16 = wv16 = None
+        if self.bf16:
+            v16 = ops.dropout_to_bf16(vn, p_att, sd(SITE_ATT_V))      # attention.drop(v) fused with the bf16 copy
+            wv16 = ops.to_bf16(P["attention.v_conv.weight"].view(mid, C))
         if p_att > 0:
-            v_in = ops.dropout(vn, p_att, sd(SITE_ATT_V))
+            v_in = None if self.bf16 else ops.dropout(vn, p_att, sd(SITE_ATT_V))
             q_in = new(B, Q)
             ops.add2d(qf, Dc, None, 0, q_in, Q, B, Q)
             ops.dropout(q_in, p_att, sd(SITE_ATT_Q), out=q_in)
@@ -225,8 +252,12 @@ class Engine:
         xs = new(B * Pn, mid)
         mode = self.att_mode
         vprime = new(B * Pn, mid) if (mode == 1 and keep) else None
-        ops.gemm(v_in, P["attention.v_conv.weight"], xs, B * Pn, mid, C, rowgroup=(qp if mode != 2 else None),
-                 rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, aux=vprime, tag=21)
+        if self.bf16:
+            ops.gemm_bf16(v16.view(B * Pn, C), wv16, xs, B * Pn, mid, C, rowgroup=(qp if mode != 2 else None),
+                          rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, aux=vprime, tag=21)
+        else:
+            ops.gemm(v_in, P["attention.v_conv.weight"], xs, B * Pn, mid, C, rowgroup=(qp if mode != 2 else None),
+                     rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, aux=vprime, tag=21)
         wx = P["attention.x_conv.weight"]
         score = ops.att_score_fwd(xs, wx.view(G, -1), P["attention.x_conv.bias"], B, Pn, p_att, sd(SITE_ATT_X),
                                   qcat=(qp if mode == 2 else None))
@@ -245,7 +276,7 @@ class Engine:
         if not keep:
             return logits, None
         ctx = SimpleNamespace(B=B, T=T, Pn=Pn, q=q, q_len=q_len, acts=acts, idxs=idxs, wds=wds, vn=vn, norm=norm,
-                              x_emb=x_emb, lstm=lstm, v_in=v_in, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
+                              x_emb=x_emb, lstm=lstm, v_in=v_in, v16=v16, wv16=wv16, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
                               c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, vprime=vprime, qp=qp, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
                               seed=seed, stages=dict(pooled=pooled, score=score, combined=combined))
         return logits, ctx
@@ -303,16 +334,31 @@ class Engine:
         ops.colsum(dwx_part, B * RS, wx.numel(), Gr["attention.x_conv.weight"])
         dqp = new(B, mid)
         ops.sum_parts(dq_part, dqp, B, RS, mid)
-        ops.gemm(dxpre, ctx.v_in, Gr["attention.v_conv.weight"], mid, C, B * Pn, transA=True, transB=False, lda=mid,
-                 ldb=C, tag=44)
         wv = P["attention.v_conv.weight"]
-        if ctx.p_att > 0:
-            dv_in = new(B * Pn, C)
-            ops.gemm(dxpre, wv, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
-            ops.dropout(dv_in, ctx.p_att, sd(SITE_ATT_V), out=dv_in)
-            ops.add(dvn, dv_in, dvn)
+        if self.bf16:
+            # both v_conv gradient products on bf16 MFMA: dW = dx'^T . v_in (both operands reduction-major),
+            # dv_in = dx' . Wv (Wv [mid][C] as the [K][N] operand); one conversion pass over dx'
+            dx16 = ops.to_bf16(dxpre)
+            ops.gemm_bf16(dx16, ctx.v16.view(B * Pn, C), Gr["attention.v_conv.weight"].view(mid, C), mid, C, B * Pn,
+                          transA=True, transB=False, lda=mid, ldb=C, tag=44)
+            if ctx.p_att > 0:
+                dv_in = new(B * Pn, C)
+                ops.gemm_bf16(dx16, ctx.wv16, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
+                ops.dropout(dv_in, ctx.p_att, sd(SITE_ATT_V), out=dv_in)
+                ops.add(dvn, dv_in, dvn)
+            else:
+                ops.gemm_bf16(dx16, ctx.wv16, dvn.view(B * Pn, C), B * Pn, C, mid, transB=False, lda=mid, ldb=C,
+                              accumulate=True, tag=45)
         else:
-            ops.gemm(dxpre, wv, dvn, B * Pn, C, mid, transB=False, lda=mid, ldb=C, accumulate=True, tag=45)
+            ops.gemm(dxpre, ctx.v_in, Gr["attention.v_conv.weight"], mid, C, B * Pn, transA=True, transB=False, lda=mid,
+                     ldb=C, tag=44)
+            if ctx.p_att > 0:
+                dv_in = new(B * Pn, C)
+                ops.gemm(dxpre, wv, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
+                ops.dropout(dv_in, ctx.p_att, sd(SITE_ATT_V), out=dv_in)
+                ops.add(dvn, dv_in, dvn)
+            else:
+                ops.gemm(dxpre, wv, dvn, B * Pn, C, mid, transB=False, lda=mid, ldb=C, accumulate=True, tag=45)
         ops.gemm(dqp, ctx.q_in, Gr["attention.q_lin.weight"], mid, Q, B, transA=True, transB=False, lda=mid,
                  ldb=ctx.ld_q, tag=46)
         ops.colsum(dqp, B, mid, Gr["attention.q_lin.bias"])
@@ -400,9 +446,18 @@ class Engine:
 
         # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first
         dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE)).view_as(ctx.acts[-1])
+        if self.bf16:
+            dP = ops.to_bf16(dP)
         for l in range(self.L - 1, -1, -1):
             if l == 0 and ctx.fast0:
                 ops.conv0_wgrad(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])
+                continue
+            if self.bf16:
+                ops.conv_wgrad_bf16(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
+                                    self.stride, tag=l)
+                # the first block's weight gradient is an fp32 kernel: the gradient it consumes is written as fp32
+                dP = ops.conv_dgrad_bf16(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride,
+                                         out_dtype=torch.float32 if l == 1 else torch.bfloat16, tag=l)
                 continue
             ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
                            self.stride, tag=l)

@@ -146,7 +146,10 @@ class _VqaFunction(torch.autograd.Function):
 class VqaNet(nn.Module):
     """MI355X-native VqaNet (reference: models/model.py:7-67)."""
 
-    def __init__(self, cfg, embedding_tokens):
+    def __init__(self, cfg, embedding_tokens, compute_dtype: str = "fp32"):
+        """compute_dtype (not in the reference): "fp32" (default; the parity path, exact fp32 MFMA) or "bf16" (BASELINE
+        configs[3]: conv blocks 1.. and the v_conv products on bf16 MFMA with fp32 accumulation; parameters, LSTM,
+        reductions and Adam stay fp32)."""
         super().__init__()
         text_cfg, image_cfg = cfg["text"], cfg["image"]
         attention_cfg, classifier_cfg = cfg["attention"], cfg["classifier"]
@@ -166,7 +169,8 @@ class VqaNet(nn.Module):
         self.classifier = Classifier(in_features=glimpses * image_features + lstm_out_features,
                                      mid_features=classifier_cfg["hidden_dim"], out_features=cfg["max_answers"],
                                      drop=classifier_cfg["dropout"])
-        self._engine = Engine(cfg, embedding_tokens)
+        self.compute_dtype = compute_dtype
+        self._engine = Engine(cfg, embedding_tokens, compute_dtype)
         named = OrderedDict(self.named_parameters())
         self._names: List[str] = list(named.keys())                    # state_dict order (autograd inputs)
         self._params: List[nn.Parameter] = list(named.values())

@@ -100,14 +100,15 @@ def conv0_supported(Ci: int, H: int, W: int, Co: int, stride: int) -> bool:
     return bool(_lib.load().vqa_conv0_supported(Ci, H, W, Co, stride))
 
 
-def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
-    """First conv block straight from the NCHW image: (pooled NHWC [B,Hp,Wp,Co], argmax uint8)."""
+def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype=torch.float32):
+    """First conv block straight from the NCHW image: (pooled NHWC [B,Hp,Wp,Co] fp32 or bf16, argmax uint8)."""
     B, Ci, H, W = x_nchw.shape
     Co = w.shape[0]
     Hp, Wp = conv_out_hw(H, W, 1)
-    pooled = torch.empty(B, Hp, Wp, Co, dtype=torch.float32, device=x_nchw.device)
+    pooled = torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x_nchw.device)
     amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x_nchw.device)
-    call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(pooled), ptr(amax), B, Ci, H, W, Co, stream())
+    call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(pooled), int(out_dtype == torch.bfloat16),
+         ptr(amax), B, Ci, H, W, Co, stream())
     return pooled, amax
 
 
@@ -301,6 +302,98 @@ def half_to_float(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     call("vqa_half_to_float", ptr(x), ptr(y), x.numel(), stream())
     return y
+
+
+# ---------------------------------------------------------------------------- bf16 path (BASELINE configs[3])
+def to_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 -> bf16 copy (round to nearest even) by the library's converter."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call("vqa_f32_to_bf16", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def dropout_to_bf16(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call("vqa_dropout_to_bf16", ptr(x), ptr(y), x.numel(), p, seed, stream())
+    return y
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call("vqa_bf16_to_f32", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def to_bf16_transposed(x: torch.Tensor) -> torch.Tensor:
+    """[rows, cols] fp32 -> [cols, rows] bf16."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    rows, cols = x.shape
+    y = torch.empty(cols, rows, dtype=torch.bfloat16, device=x.device)
+    call("vqa_f32_to_bf16_transpose", ptr(x), ptr(y), rows, cols, stream())
+    return y
+
+
+def gemm_bf16(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, *, transA=False, transB=True,
+              lda=None, ldb=None, ldc=None, bias1=None, bias2=None, rowgroup=None, rg_div=1, rg_op=0, relu=False,
+              accumulate=False, aux=None, tag=0) -> torch.Tensor:
+    """vqa_gemm with bf16 A / B (fp32 accumulation); C fp32 or bf16 by its dtype."""
+    lib = _lib.load()
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C.dtype in (torch.float32, torch.bfloat16)
+    lda = lda if lda is not None else (M if transA else K)
+    ldb = ldb if ldb is not None else (K if transB else N)
+    ldc = ldc if ldc is not None else N
+    nbytes = lib.vqa_gemm_bf16_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, A.device) if nbytes else None
+    call("vqa_gemm_bf16", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(C), ldc, int(C.dtype == torch.bfloat16),
+         M, N, K, ptr(bias1), ptr(bias2), ptr(rowgroup), (rowgroup.stride(0) if rowgroup is not None else 0),
+         rg_div, rg_op, int(relu), int(accumulate), ptr(aux), ptr(ws), (ws.numel() * 4 if ws is not None else 0),
+         tag, stream())
+    return C
+
+
+def conv_pack_weights_bf16(w: torch.Tensor, CiP: int, need_wd: bool = True):
+    """fp32 [Co,Ci,3,3] -> bf16 wfT [Co, 9*CiP] and wdT [CiP, 9*Co] (K index = (tap, channel))."""
+    Co, Ci = w.shape[0], w.shape[1]
+    wfT = torch.empty(Co, 9 * CiP, dtype=torch.bfloat16, device=w.device)
+    wdT = torch.empty(CiP, 9 * Co, dtype=torch.bfloat16, device=w.device) if need_wd else None
+    call("vqa_conv_pack_weights_bf16", ptr(w), ptr(wfT), ptr(wdT), Co, Ci, CiP, stream())
+    return wfT, wdT
+
+
+def conv_fwd_bf16(x: torch.Tensor, wfT: torch.Tensor, bias: torch.Tensor, stride: int = 1, out_dtype=torch.bfloat16,
+                  tag: int = 0):
+    """x NHWC bf16 [B,H,W,CiP] -> (pooled [B,Hp,Wp,Co] bf16 or fp32, argmax uint8)."""
+    assert x.dtype == torch.bfloat16 and wfT.dtype == torch.bfloat16
+    B, H, W, CiP = x.shape
+    Co = wfT.shape[0]
+    Hp, Wp = conv_out_hw(H, W, stride)
+    pooled = torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x.device)
+    amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x.device)
+    call("vqa_conv3x3_relu_pool_fwd_bf16", ptr(x), ptr(wfT), ptr(bias), ptr(pooled), int(out_dtype == torch.bfloat16),
+         ptr(amax), B, H, W, CiP, Co, stride, tag, stream())
+    return pooled, amax
+
+
+def conv_dgrad_bf16(dpooled, amax, wdT, x_shape, stride: int = 1, out_dtype=torch.bfloat16, tag: int = 0):
+    assert dpooled.dtype == torch.bfloat16
+    B, H, W, CiP = x_shape
+    Co = dpooled.shape[3]
+    dx = torch.empty(B, H, W, CiP, dtype=out_dtype, device=dpooled.device)
+    call("vqa_conv3x3_dgrad_bf16", ptr(dpooled), ptr(amax), ptr(wdT), ptr(dx), int(out_dtype == torch.bfloat16), B, H, W,
+         CiP, Co, stride, tag, stream())
+    return dx
+
+
+def conv_wgrad_bf16(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: int = 1, tag: int = 0):
+    assert x.dtype == torch.bfloat16 and dpooled.dtype == torch.bfloat16
+    lib = _lib.load()
+    B, H, W, CiP = x.shape
+    Co, Ci = dw.shape[0], dw.shape[1]
+    ws = workspace(lib.vqa_conv3x3_wgrad_bf16_workspace_bytes(B, H, W, CiP, Co, stride), x.device)
+    call("vqa_conv3x3_wgrad_bf16", ptr(x), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co, stride,
+         ptr(ws), ws.numel() * 4, tag, stream())
 
 
 def scale_by(x, scalar_dev):

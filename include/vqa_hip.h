@@ -103,8 +103,9 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
  * NCHW image directly (no layout conversion), weights/bias in torch layout, same pooled/argmax outputs
  * as vqa_conv3x3_relu_pool_fwd.  vqa_conv0_supported() tells whether a shape takes this path. */
 int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride);
-int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, float* pooled,
-                            uint8_t* argmax, int B, int Ci, int H, int W, int Co, vqa_stream_t stream);
+int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, void* pooled,
+                            int pooled_is_bf16 /* bf16 path: P_0 stored as bf16 */, uint8_t* argmax, int B, int Ci,
+                            int H, int W, int Co, vqa_stream_t stream);
 int64_t vqa_conv0_wgrad_workspace_bytes(int Co);
 int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias,
                     int B, int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes,
@@ -237,6 +238,43 @@ int vqa_scale_by(float* x, int64_t n, const float* scalar, vqa_stream_t stream);
  * (preprocessing/data_preprocessing.py:167-176); here the fp16 batch is uploaded as is (half the PCIe bytes)
  * and widened on the device.  x and y 16-byte aligned or n small; layout unchanged (NCHW). */
 int vqa_half_to_float(const void* x_f16, float* y, int64_t n, vqa_stream_t stream);
+
+/* ---- bf16 path (BASELINE configs[3]: bf16 MFMA conv / FC, fp32 accumulate, fp32 LSTM) -------------------
+ * Opt-in second instantiation of the engine on v_mfma_f32_32x32x16_bf16.  Parameters, Adam state, the LSTM and
+ * every reduction stay fp32; bf16 tensors are raw uint16 buffers (IEEE bfloat16, round to nearest even).
+ * The fp32 entry points above remain the parity path. */
+/* y = bf16(x) / y = float(x) element-wise; y[c][r] = bf16(x[r][c]) (a weight's bf16 copy in the other orientation) */
+int vqa_f32_to_bf16(const float* x, void* y_bf16, int64_t n, vqa_stream_t stream);
+int vqa_bf16_to_f32(const void* x_bf16, float* y, int64_t n, vqa_stream_t stream);
+int vqa_f32_to_bf16_transpose(const float* x, void* y_bf16, int rows, int cols, vqa_stream_t stream);
+/* y = bf16(x * keep(seed, i) / (1-p)): nn.Dropout fused with the bf16 copy (attention.drop on v, model.py:185) */
+int vqa_dropout_to_bf16(const float* x, void* y_bf16, int64_t n, float p, uint64_t seed, vqa_stream_t stream);
+/* vqa_gemm with bf16 A and B (same layouts / trans flags; leading dimensions in ELEMENTS, multiples of 8; K % 8 == 0;
+ * a reduction-major operand needs its row length % 8 == 0), fp32 accumulation, the same fused epilogue; C is fp32,
+ * or bf16 when c_is_bf16 (then no accumulate).  bias / rowgroup / aux stay fp32. */
+int64_t vqa_gemm_bf16_workspace_bytes(int M, int N, int K);
+int vqa_gemm_bf16(const void* A, int64_t lda, int transA, const void* B, int64_t ldb, int transB, void* C,
+                  int64_t ldc, int c_is_bf16, int M, int N, int K, const float* bias1, const float* bias2,
+                  const float* rowgroup, int64_t rg_ld, int rg_div, int rg_op, int relu, int accumulate,
+                  float* aux, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
+
+/* Convolution blocks of the bf16 path (models/model.py:80-82 and their autograd): activations NHWC bf16, weights
+ * re-packed per step to bf16 as wfT [Co][9*CiP] and wdT [CiP][9*Co] (K index = (tap, channel)), arg-max bytes and
+ * semantics as in the fp32 entry points, fp32 accumulation, fp32 weight / bias gradients.
+ *   forward: CiP % 64 == 0; pooled is bf16, or fp32 when pooled_is_bf16 == 0 (the last block feeds the fp32 L2 norm);
+ *   dgrad:   Co % 64 == 0; dx is bf16, or fp32 when dx_is_bf16 == 0;
+ *   wgrad:   CiP, Co multiples of 8; both operands reach the MFMAs through ds_read_b64_tr_b16 (reduction-major). */
+int vqa_conv_pack_weights_bf16(const float* w, void* wfT, void* wdT /* may be NULL */, int Co, int Ci, int CiP,
+                               vqa_stream_t stream);
+int vqa_conv3x3_relu_pool_fwd_bf16(const void* x, const void* wfT, const float* bias, void* pooled,
+                                   int pooled_is_bf16, uint8_t* argmax, int B, int H, int W, int CiP, int Co,
+                                   int stride, int tag, vqa_stream_t stream);
+int vqa_conv3x3_dgrad_bf16(const void* dpooled, const uint8_t* argmax, const void* wdT, void* dx, int dx_is_bf16,
+                           int B, int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream);
+int64_t vqa_conv3x3_wgrad_bf16_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride);
+int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* argmax, float* dw, float* dbias,
+                           int B, int H, int W, int CiP, int Ci, int Co, int stride, float* workspace,
+                           int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
 /* ---- optimiser: torch.optim.Adam defaults over one flat buffer (train.py:55,80) ------------- */
 int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

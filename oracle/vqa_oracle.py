@@ -58,15 +58,47 @@ def _drop(x: Tensor, masks: Optional[dict], site: str) -> Tensor:
     return x * masks[site].to(x.dtype)
 
 
+# bf16 path (BASELINE configs[3]): the same oracle with the operands of the re-typed contractions rounded to
+# bfloat16 where the HIP path stores / stages them as bf16 (round to nearest even; products of two bf16 values are
+# exact in fp32, accumulation stays fp32): the activations between conv blocks, the conv weights of blocks >= 1, the
+# v_conv input and weight; in backward, the gradients the HIP path stores as bf16 (dP of the conv blocks >= 1, dx').
+def rb(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundFB(torch.autograd.Function):
+    """identity whose forward value and / or backward gradient are rounded to bf16"""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return rb(x) if fwd else x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (rb(g) if ctx.bwd else g), None, None
+
+
+def _rfb(x: Tensor, fwd: bool, bwd: bool, on: bool) -> Tensor:
+    return _RoundFB.apply(x, fwd, bwd) if on else x
+
+
+def _w16(w: Tensor, on: bool) -> Tensor:
+    """bf16 copy of an fp32 master weight (straight-through: the gradient goes to the master weight unchanged)"""
+    return w + (rb(w) - w).detach() if on else w
+
+
 def image_encoder(sd: Dict[str, Tensor], v: Tensor, stride: int = 1,
-                  stages: Optional[dict] = None, masks: Optional[dict] = None) -> Tensor:
+                  stages: Optional[dict] = None, masks: Optional[dict] = None, bf16: bool = False) -> Tensor:
     """ImageNet2.forward (model.py:79-84): the conv blocks, then image.drop on the last pooled map."""
-    i = 0
-    while f"image.conv{i}.weight" in sd:
-        v = conv_relu_pool(v, sd[f"image.conv{i}.weight"], sd[f"image.conv{i}.bias"], stride)
+    n = sum(1 for k in sd if k.startswith("image.conv") and k.endswith(".weight"))
+    for i in range(n):
+        v = conv_relu_pool(v, _w16(sd[f"image.conv{i}.weight"], bf16 and i > 0), sd[f"image.conv{i}.bias"], stride)
+        # bf16 path: pooled maps between blocks are stored as bf16 (the last one stays fp32); the gradient that
+        # enters block i's backward is bf16 for i >= 1 (the first block's weight-gradient kernel is fp32)
+        v = _rfb(v, fwd=i < n - 1, bwd=i > 0, on=bf16)
         if stages is not None:
             stages[f"pool{i}"] = v
-        i += 1
     return _drop(v, masks, "image")                                  # model.py:84
 
 
@@ -132,10 +164,11 @@ def question_encoder(sd: Dict[str, Tensor], q: Tensor, q_len: Tensor,
 # attention — reference models/model.py:169-195, 208-231
 # --------------------------------------------------------------------------
 def attention_scores(sd: Dict[str, Tensor], v: Tensor, q: Tensor, do_option: str = "+",
-                     masks: Optional[dict] = None) -> Tensor:
+                     masks: Optional[dict] = None, bf16: bool = False) -> Tensor:
     """Attention.forward (model.py:183-195).  v [B,C,g,g], q [B,Q] -> [B,G,g,g]."""
-    wv = sd["attention.v_conv.weight"]          # [mid, C, 1, 1], no bias (model.py:173)
-    vv = torch.einsum("bchw,mc->bmhw", _drop(v, masks, "att_v"), wv[:, :, 0, 0])                  # model.py:185
+    wv = _w16(sd["attention.v_conv.weight"], bf16)          # [mid, C, 1, 1], no bias (model.py:173)
+    v_in = _rfb(_drop(v, masks, "att_v"), fwd=True, bwd=False, on=bf16)                          # model.py:185
+    vv = _rfb(torch.einsum("bchw,mc->bmhw", v_in, wv[:, :, 0, 0]), fwd=False, bwd=True, on=bf16)
     qq = _drop(q, masks, "att_q") @ sd["attention.q_lin.weight"].t() + sd["attention.q_lin.bias"]  # model.py:186
     qq = qq[:, :, None, None].expand_as(vv)     # tile_question_over_image (model.py:224-231)
     if do_option == "*":
@@ -170,13 +203,14 @@ def classifier(sd: Dict[str, Tensor], x: Tensor, masks: Optional[dict] = None) -
 
 
 def vqa_forward(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: Tensor,
-                stages: Optional[dict] = None, masks: Optional[dict] = None) -> Tensor:
+                stages: Optional[dict] = None, masks: Optional[dict] = None, bf16: bool = False) -> Tensor:
     """VqaNet.forward (model.py:53-67). Returns logits [B, max_answers].
-    masks=None: eval mode; masks = {site: keep-scale tensor}: train mode with those dropout masks (MASK_SITES)."""
-    img = image_encoder(sd, v, cfg["image"]["stride"], stages, masks)
+    masks=None: eval mode; masks = {site: keep-scale tensor}: train mode with those dropout masks (MASK_SITES);
+    bf16: the bf16 path's rounding points (see rb above)."""
+    img = image_encoder(sd, v, cfg["image"]["stride"], stages, masks, bf16)
     vn = l2_normalise(img)
     qf = question_encoder(sd, q, q_len, cfg["text"]["bidirectional"], masks)
-    att = attention_scores(sd, vn, qf, cfg["attention"]["do_option"], masks)
+    att = attention_scores(sd, vn, qf, cfg["attention"]["do_option"], masks, bf16)
     wv, probs = image_question_attention(vn, att)              # the weighted sum sees v WITHOUT attention.drop
     logits = classifier(sd, torch.cat([wv, qf], dim=1), masks)
     if stages is not None:
@@ -231,14 +265,14 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
 # --------------------------------------------------------------------------
 def loss_and_grads(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: Tensor,
                    a_indices: Tensor, a_values: Tensor,
-                   loss_scale_batch: Optional[int] = None, masks: Optional[dict] = None
+                   loss_scale_batch: Optional[int] = None, masks: Optional[dict] = None, bf16: bool = False
                    ) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
     """Forward + soft-CE + backward by autograd over the restated ops.
 
     ``loss_scale_batch`` overrides the divisor B (used by the data-parallel
     tests, where each rank divides by the GLOBAL batch); ``masks``: train mode, see vqa_forward."""
     params = {k: t.detach().clone().requires_grad_(True) for k, t in sd.items()}
-    logits = vqa_forward(params, cfg, v, q, q_len, masks=masks)
+    logits = vqa_forward(params, cfg, v, q, q_len, masks=masks, bf16=bf16)
     loss = soft_ce_loss(logits, a_indices, a_values)
     if loss_scale_batch is not None:
         loss = loss * (logits.shape[0] / float(loss_scale_batch))

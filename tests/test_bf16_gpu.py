@@ -1,0 +1,194 @@
+"""GPU parity of the bf16 path (BASELINE configs[3]) through the C ABI.
+
+Reference for every bf16 kernel: the same operator in float64 on operands ROUNDED TO bf16 (products of two bf16
+values are exact in fp32, so what remains is the fp32 accumulation order): tolerance 3e-6 * sqrt(K) relative to the
+largest result for fp32 outputs, one bf16 ulp (2^-8 relative) for bf16 outputs -- stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from dl_vqa_amd import ops
+    return ops
+
+
+def rb(x):
+    """round to bf16 and back (what the bf16 storage does)"""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+
+
+def check(name, got, ref, tol):
+    e = rel_err(got, ref)
+    print(f"[parity-bf16] {name}: max|err|/max|ref| = {e:.3e} (tol {tol:.1e})")
+    assert e <= tol, f"{name}: {e} > {tol}"
+
+
+def test_converters_round_to_nearest_even():
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000 * 37 + 5, generator=g) * 3
+    x[:4] = torch.tensor([1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -0.0, 65280.0])    # ties: to even mantissa
+    y = ops.to_bf16(x.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.to_f32(y).cpu(), x.to(torch.bfloat16).float())
+    w = torch.randn(70, 45, generator=g)
+    assert torch.equal(ops.to_bf16_transposed(w.to(DEV)).cpu(), w.t().contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (304, 200, 96), (64, 64, 64), (8, 8, 8), (256, 1024, 2560),
+                                   (1032, 264, 3584), (136, 4096, 304), (72, 56, 40), (200, 136, 1000)])
+@pytest.mark.parametrize("transA,transB", [(False, True), (False, False), (True, True), (True, False)])
+def test_gemm_bf16_layouts(M, N, K, transA, transB):
+    """Every operand layout: k-contiguous rows (the fp32 engine's LDS image reused) and reduction-major rows (the
+    ds_read_b64_tr_b16 transpose-read image); asymmetric random data, tiles with edges, K tails, split-K plans."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = rb(torch.randn(M, K, generator=g))
+    Bm = rb(torch.randn(K, N, generator=g))
+    ref = A.double() @ Bm.double()
+    As = (A.t().contiguous() if transA else A).to(torch.bfloat16).to(DEV)      # [K][M] or [M][K]
+    Bs = (Bm.t().contiguous() if transB else Bm).to(torch.bfloat16).to(DEV)    # [N][K] or [K][N]
+    Cd = torch.full((M, N + 3), 7.0, device=DEV)
+    ops.gemm_bf16(As, Bs, Cd, M, N, K, transA=transA, transB=transB, ldc=N + 3)
+    torch.cuda.synchronize()
+    check(f"gemm_bf16 {M}x{N}x{K} tA={transA} tB={transB}", Cd[:, :N], ref, 3e-6 * math.sqrt(K))
+    assert float((Cd[:, N:] - 7.0).abs().max()) == 0.0
+
+
+def test_gemm_bf16_epilogue_and_bf16_output():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    Bn, P, K, N = 3, 7, 40, 40
+    M = Bn * P
+    A, W = rb(torch.randn(M, K, generator=g)), rb(torch.randn(N, K, generator=g))
+    b1, rg = torch.randn(N, generator=g), torch.randn(Bn, N, generator=g)
+    acc = A.double() @ W.double().t()
+    ref = torch.relu(acc + rg.double().repeat_interleave(P, dim=0) + b1.double())
+    Cf = torch.empty(M, N, device=DEV)
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    for C in (Cf, Cb):
+        ops.gemm_bf16(A.to(torch.bfloat16).to(DEV), W.to(torch.bfloat16).to(DEV), C, M, N, K, bias1=b1.to(DEV),
+                      rowgroup=rg.to(DEV), rg_div=P, relu=True)
+    torch.cuda.synchronize()
+    check("gemm_bf16 epilogue fp32 out", Cf, ref, 1e-5)
+    check("gemm_bf16 epilogue bf16 out", Cb.float(), ref, 2 ** -8)
+    assert torch.equal(Cb.cpu(), Cf.cpu().to(torch.bfloat16))        # the bf16 result is the rounded fp32 result
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,stride", [(2, 30, 30, 64, 128, 1), (1, 30, 34, 128, 256, 1), (3, 22, 20, 64, 64, 1),
+                                                (2, 41, 37, 64, 128, 2), (2, 58, 58, 64, 128, 1)])
+def test_conv_bf16_fwd_dgrad_wgrad(B, H, W, Ci, Co, stride):
+    """The three bf16 convolution kernels against float64 autograd on bf16-rounded x, w, dy: forward (bf16 and fp32
+    outputs), dgrad (bf16 and fp32 outputs), wgrad + bias gradient (fp32)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Ci)
+    x = rb(torch.randn(B, Ci, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci))
+    b = torch.randn(Co, generator=g) * 0.1
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.max_pool2d(torch.relu(F.conv2d(xr, wr, br, stride=stride)), 2, 2)
+    dy = rb(torch.randn(yr.shape, generator=g))
+    yr.backward(dy.double())
+
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    wfT, wdT = ops.conv_pack_weights_bf16(w.to(DEV), Ci)
+    p32, amax = ops.conv_fwd_bf16(xd, wfT, b.to(DEV), stride, out_dtype=torch.float32)
+    p16, amax2 = ops.conv_fwd_bf16(xd, wfT, b.to(DEV), stride)
+    torch.cuda.synchronize()
+    tag = f"{B,H,W,Ci,Co,stride}"
+    check(f"conv_bf16 fwd fp32-out {tag}", p32.permute(0, 3, 1, 2), yr, 3e-6 * math.sqrt(9 * Ci))
+    assert torch.equal(amax, amax2) and torch.equal(p16, p32.to(torch.bfloat16))
+    assert bool(((p32 == 0) == (amax == 4)).all())
+
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    dx32 = ops.conv_dgrad_bf16(dyd, amax, wdT, xd.shape, stride, out_dtype=torch.float32)
+    dx16 = ops.conv_dgrad_bf16(dyd, amax, wdT, xd.shape, stride)
+    dw, db = torch.empty(Co, Ci, 3, 3, device=DEV), torch.empty(Co, device=DEV)
+    ops.conv_wgrad_bf16(xd, dyd, amax, dw, db, stride)
+    torch.cuda.synchronize()
+    check(f"conv_bf16 dgrad fp32-out {tag}", dx32.permute(0, 3, 1, 2), xr.grad, 5e-6 * math.sqrt(9 * Co))
+    assert torch.equal(dx16, dx32.to(torch.bfloat16))
+    check(f"conv_bf16 wgrad {tag}", dw, wr.grad, 2e-5)
+    check(f"conv_bf16 bias grad {tag}", db, br.grad, 2e-5)
+
+
+# ----------------------------------------------------------------------------- the whole module in bf16 mode
+def bf16_cfg(do_option="+", p=0.0):
+    return {
+        "text": {"question_features": 32, "embedding_features": 20, "dropout": p, "num_lstm_layers": 1, "bidirectional": True},
+        "image": {"kernel_size": 3, "dropout": p, "num_channels": [3, 64, 64, 128], "stride": 1, "do_skip_connection": False},
+        "attention": {"hidden_dim": 64, "glimpses": 2, "do_option": do_option, "dropout": p},
+        "classifier": {"hidden_dim": 40, "dropout": p},
+        "max_answers": 24,
+    }
+
+
+@pytest.mark.parametrize("do_option,train", [("+", False), ("+", True), ("*", True), ("|", False)])
+def test_bf16_module_matches_bf16_oracle(do_option, train):
+    """VqaNet(compute_dtype="bf16") against the oracle with the SAME rounding points (oracle.vqa_forward(bf16=True):
+    activations between conv blocks, conv / v_conv weights, the v_conv input, and in backward the stored bf16
+    gradients), eval mode and train mode with shared dropout masks.  Tolerance: the two sides differ by fp32
+    accumulation order, which can flip a bf16 rounding (2^-9 relative) of a few stored elements: logits 5e-5
+    absolute, gradients 2e-2 of the largest entry -- an order of magnitude below the distance to the fp32 result,
+    which is asserted as well."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd import VqaNet
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    from tests.hip_masks import hip_masks
+    cfg = bf16_cfg(do_option, 0.3 if train else 0.0)
+    V, B, S, T = 50, 3, 48, 6
+    torch.manual_seed(3)
+    m = VqaNet(cfg, V, compute_dtype="bf16").to(DEV)
+    m.train(train)
+    sd = {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}
+    v, q, a_idx, a_val, _, _, ql = O.synthetic_batch(B, S, T, V, 24, seed=5)
+    torch.manual_seed(9)
+    y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
+    loss, _ = soft_ce_loss_and_score(y, a_idx.to(DEV), a_val.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ctx = m._last_ctx
+    assert ctx.acts[1].dtype == torch.bfloat16 and ctx.acts[2].dtype == torch.bfloat16 and ctx.acts[3].dtype == torch.float32
+    masks = hip_masks(m._engine, ctx.seed, B, T, ctx.acts[-1].shape[1], DEV) if train else None
+    y_ref, loss_ref, g_ref = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks, bf16=True)
+    y_f32, _, g_f32 = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks)
+    err = float((y.detach().cpu() - y_ref).abs().max())
+    dist = float((y_f32 - y_ref).abs().max())
+    print(f"[parity-bf16] module ({do_option}, train={train}) logits |err| vs bf16 oracle {err:.3e}; bf16 vs fp32 oracle {dist:.3e}")
+    assert err < 5e-5 and err < 0.5 * dist          # measured 1.2e-6 .. 1.8e-6 against 9e-5 .. 1.1e-4
+    assert abs(float(loss) - float(loss_ref)) < 5e-5
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = g_ref[k]
+        scale = max(float(ref.abs().max()), 1e-12)
+        if k == "attention.x_conv.bias":
+            assert float(p.grad.abs().max()) < 1e-6
+            continue
+        e = float((p.grad.cpu() - ref).abs().max()) / scale
+        d = float((g_f32[k] - ref).abs().max()) / scale
+        print(f"[parity-bf16] module ({do_option}, train={train}) grad {k}: vs bf16 oracle {e:.3e}; bf16 vs fp32 oracle {d:.3e}")
+        worst = max(worst, e)
+        assert e < 2e-2, (k, e)
+    print(f"[parity-bf16] worst gradient error {worst:.3e}")
+
+
+def test_bf16_path_rejects_unsupported_configs():
+    from dl_vqa_amd import VqaNet
+    cfg = bf16_cfg()
+    cfg["image"]["num_channels"] = [3, 8, 16, 32]
+    with pytest.raises(ValueError, match="multiples of 64"):
+        VqaNet(cfg, 10, compute_dtype="bf16")
+    with pytest.raises(ValueError, match="compute_dtype"):
+        VqaNet(bf16_cfg(), 10, compute_dtype="fp8")

@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA": ~2.5 PF dense (the 5 PF figure is 2:1 sparse)
 
 
 def reference_cfg(answers: int) -> dict:
@@ -126,6 +127,12 @@ def main():
     ap.add_argument("--tokens", type=int, default=14)
     ap.add_argument("--answers", type=int, default=1000)
     ap.add_argument("--vocab", type=int, default=5000)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the headline / parity path (BASELINE configs[1]); bf16 = the bf16 MFMA conv/FC path "
+                         "(configs[3]: use with --batch 512 --size 448); never the headline")
+    ap.add_argument("--stream-steps", type=int, default=3,
+                    help="extra steps after the timed region in which the HBM-bound kernel families are bracketed "
+                         "with HIP events (the `streaming` table); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="diagnostic only: dropout off")
     ap.add_argument("--force-dist", action="store_true",
@@ -156,7 +163,7 @@ def main():
     cfg = reference_cfg(args.answers)
     B, S, T, V, A = args.batch, args.size, args.tokens, args.vocab, args.answers
     torch.manual_seed(1)                                   # config.yaml:9 seed
-    model = VqaNet(cfg, V).to(dev)
+    model = VqaNet(cfg, V, compute_dtype=args.dtype).to(dev)
     model.train(not args.eval_mode)
     if use_dist:
         DataParallel(model)
@@ -179,7 +186,7 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    lib.vqa_prof_arm(4, -1)                      # VQA_K_COUNT: bracket every kernel family with HIP events
+    lib.vqa_prof_arm_mask(0b1111, -1)            # bracket the MFMA kernel families (GEMM, conv fwd / dgrad / wgrad) with HIP events
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -194,6 +201,18 @@ def main():
     g_ms = (ctypes.c_float * cap)()
     n_groups = lib.vqa_prof_read_groups(g_id, g_tag, g_n, g_ms, cap)
     lib.vqa_prof_arm(-1, -1)
+    # HBM-bound stages: a few extra steps OUTSIDE the timed region with their families bracketed as well
+    stream_rows = []
+    if args.stream_steps > 0 and not use_dist:      # single GPU only: under DP every rank would have to step
+        lib.vqa_prof_arm_mask(((1 << _lib.K_COUNT) - 1) & ~0b1111, -1)
+        for _ in range(args.stream_steps):
+            step()
+        torch.cuda.synchronize()
+        s_id, s_tag, s_n = (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+        s_ms = (ctypes.c_float * cap)()
+        ns = lib.vqa_prof_read_groups(s_id, s_tag, s_n, s_ms, cap)
+        lib.vqa_prof_arm(-1, -1)
+        stream_rows = [(s_id[k], s_tag[k], s_n[k], s_ms[k]) for k in range(ns)]
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -206,7 +225,8 @@ def main():
         shapes, _ = conv_shapes(S, cfg["image"]["num_channels"], cfg["image"]["stride"])
         # live per-kernel table: every convolution kernel of the step, algorithmic FLOPs / measured launch time
         traffic_db = {}
-        if B == 256 and S == 224:
+        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+        if B == 256 and S == 224 and args.dtype == "fp32":
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_conv1_traffic.json")) as f:
                     traffic_db = json.load(f)
@@ -221,9 +241,10 @@ def main():
             flops_launch = 2.0 * B * Ho * Wo * co * 9 * ci
             avg_ms = g_ms[g] / g_n[g]
             ach = flops_launch / (avg_ms * 1e-3) / 1e12
+            kpeak = BF16_MFMA_PEAK_TFLOPS if (args.dtype == "bf16" and tag > 0) else FP32_MFMA_PEAK_TFLOPS
             kernels.append({"kernel": f"{fam}[conv{tag}]", "launches": g_n[g], "avg_launch_ms": round(avg_ms, 4),
                             "algorithmic_gflop_per_launch": round(flops_launch / 1e9, 2),
-                            "achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                            "achieved": round(ach, 2), "frac": round(ach / kpeak, 4), "peak": kpeak,
                             "traffic": (int(traffic_db[f"{fam}:{tag}"]["hbm_bytes_corrected"])
                                         if f"{fam}:{tag}" in traffic_db else None),
                             "ms_per_step": round(g_ms[g] / args.steps, 3), "family": fam})
@@ -247,28 +268,64 @@ def main():
             ach = gf / tot_ms                     # GFLOP / ms = TFLOP/s
             tr = [k["traffic"] for k in sel]
             roofline = {"bound": "mfma", "kernel": "+".join(k["kernel"] for k in sel), "achieved": round(ach, 2),
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": (int(sum(t * k["launches"] for t, k in zip(tr, sel)) / n) if all(t is not None for t in tr) else None),
                         "avg_launch_ms": round(tot_ms / n, 4), "launches": n,
                         "algorithmic_gflop_per_launch": round(gf / n, 2),
                         "traffic_unit": "bytes/launch (PMC, profiles/r01_conv1_traffic.json)"}
         for k in kernels:
             del k["family"]
+        # HBM-bound stages: algorithmic bytes per launch / measured launch time, against the 8 TB/s
+        # HBM3E peak (6.3 TB/s is what a plain copy achieves on this chip)
+        conv_out, g_ = conv_shapes(S, cfg["image"]["num_channels"], cfg["image"]["stride"])
+        Pn, Cc, mid_, G_ = g_ * g_, cfg["image"]["num_channels"][-1], cfg["attention"]["hidden_dim"], cfg["attention"]["glimpses"]
+        Mrows = B * Pn
+        n_params = sum(p.numel() for p in model.parameters())
+        alg = {
+            (_lib.K_L2NORM_FWD, -1): ("l2norm_fwd", 2 * Mrows * Cc * 4),
+            (_lib.K_L2NORM_BWD, -1): ("l2norm_bwd", 3 * Mrows * Cc * 4),
+            (_lib.K_ATT_SCORE_FWD, -1): ("att_score_fwd", Mrows * mid_ * 4 + Mrows * G_ * 4),
+            (_lib.K_ATT_SCORE_BWD, -1): ("att_score_bwd", 2 * Mrows * mid_ * 4 + Mrows * G_ * 4),
+            (_lib.K_ATT_APPLY_FWD, -1): ("att_apply_fwd", Mrows * Cc * 4 + 2 * Mrows * G_ * 4),
+            (_lib.K_ATT_APPLY_BWD, -1): ("att_apply_bwd", 2 * Mrows * Cc * 4 + 3 * Mrows * G_ * 4),
+            (_lib.K_DROPOUT, 1): ("dropout[v]", (2 * Mrows * Cc * 4) if args.dtype == "fp32" else None),
+            (_lib.K_ADAM, -1): ("adam", 7 * n_params * 4),
+            (_lib.K_SOFTCE, -1): ("softce_fwd_bwd", 2 * B * A * 4),
+        }
+        streaming = []
+        for fid, tag, n_l, ms in stream_rows:
+            if fid == _lib.K_LSTM_SEQ and n_l:
+                streaming.append({"kernel": "lstm_seq_" + ("fwd" if tag == 0 else "bwd"), "launches": n_l,
+                                  "avg_call_ms": round(ms / n_l, 4), "note": "whole recurrence, both directions"})
+                continue
+            name, nbytes = alg.get((fid, tag), (None, None))
+            if name is None or not nbytes or not n_l:
+                continue
+            avg_ms = ms / n_l
+            gbs = nbytes / (avg_ms * 1e-3) / 1e9
+            streaming.append({"kernel": name, "launches": n_l, "avg_launch_ms": round(avg_ms, 4),
+                              "algorithmic_bytes_per_launch": int(nbytes), "achieved_GBps": round(gbs, 1),
+                              "frac_of_8000": round(gbs / 8000.0, 4), "frac_of_6300_achievable": round(gbs / 6300.0, 4)})
         gflop_sample = step_flops_per_sample(cfg, S, T) / 1e9
         out = {
             "metric": "VQA samples/sec (train step)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"VqaNet train step (fwd+softCE+bwd+{'allreduce+' if use_dist else ''}Adam), "
                                    f"batch {B}/GPU, {S}x{S} images, {T}-token questions, {A}-way head, "
-                                   f"{'eval' if args.eval_mode else 'train'} mode",
+                                   f"{'eval' if args.eval_mode else 'train'} mode"
+                                   + ("" if args.dtype == "fp32" else ", bf16 MFMA conv blocks 1-2 + v_conv (fp32 accumulate), "
+                                      "fp32 first block / LSTM / reductions / Adam"),
                        "global_batch": B * world, "image_size": S, "tokens": T, "answers": A, "vocab": V,
                        "parallelism": f"dp{world}"},
             "step_gflop_per_sample": round(gflop_sample, 3),
-            "step_mfma_frac": round(value * gflop_sample / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            "step_mfma_frac": round(value * gflop_sample / 1e3 / (peak * world), 4),
+            "step_mfma_peak_tflops": peak,
             "final_loss": round(final_loss, 5),
             "roofline": roofline,
             "kernels": kernels,
+            "streaming": streaming,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, V, A, T)

@@ -21,6 +21,7 @@ PROTOTYPES = {
     "vqa_device_ok": (i32, []),
     "vqa_reload_knobs": (i32, []),
     "vqa_prof_arm": (i32, [i32, i32]),
+    "vqa_prof_arm_mask": (i32, [C.c_uint32, i32]),
     "vqa_prof_read": (i32, [C.POINTER(i32), C.POINTER(f32)]),
     "vqa_prof_read_groups": (i32, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), i32]),
     "vqa_gemm_workspace_bytes": (i64, [i32, i32, i32]),
@@ -78,6 +79,8 @@ PROTOTYPES = {
 }
 
 K_GEMM, K_CONV_FWD, K_CONV_DGRAD, K_CONV_WGRAD = 0, 1, 2, 3
+(K_L2NORM_FWD, K_L2NORM_BWD, K_ATT_SCORE_FWD, K_ATT_SCORE_BWD, K_ATT_APPLY_FWD, K_ATT_APPLY_BWD, K_ADAM, K_SOFTCE,
+ K_DROPOUT, K_LSTM_SEQ, K_COUNT) = range(4, 15)
 
 
 class LstmDir(C.Structure):

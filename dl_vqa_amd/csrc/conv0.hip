@@ -231,7 +231,7 @@ static bool c0_supported(int Ci, int H, int W, int Co, int stride) {
   int plane = 4 * rs;
   while (plane % 32 != 3) ++plane;
   const size_t wg = ((size_t)Ci * plane + 4) * 4 + (size_t)Wp * Co * 5;
-  return fwd <= 60 * 1024 && wg <= 60 * 1024;
+  return fwd <= 160 * 1024 && wg <= 160 * 1024;      // one workgroup's LDS (the launchers raise the 64 KB default)
 }
 
 constexpr int kC0Blocks = 768;   // persistent wgrad grid: 3 workgroups per CU
@@ -265,13 +265,15 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
   const int Hp = (H - 2) / 2, Wp = (W - 2) / 2, RS = c0_round_stride(W, 16);
   const size_t lds = (size_t)Ci * C0_PR * RS * 4;
   const dim3 grid((Hp + C0_FR - 1) / C0_FR, B);
-  if (pooled_is_bf16) {
-    C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_fwd_kernel<kCI, kTN, true>), grid, dim3(256), lds, (hipStream_t)stream,
-                                                x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS));
-  } else {
-    C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_fwd_kernel<kCI, kTN, false>), grid, dim3(256), lds, (hipStream_t)stream,
-                                                x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS));
-  }
+#define C0_FWD_LAUNCH(OB)                                                                                              \
+  C0_DISPATCH(Ci, Co / 32, {                                                                                           \
+    auto kern = conv0_fwd_kernel<kCI, kTN, OB>;                                                                        \
+    int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd)");                       \
+    if (rc0) return rc0;                                                                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS); \
+  })
+  if (pooled_is_bf16) { C0_FWD_LAUNCH(true); } else { C0_FWD_LAUNCH(false); }
+#undef C0_FWD_LAUNCH
   return check_hip(hipGetLastError(), "conv0_fwd launch");
 }
 
@@ -290,12 +292,21 @@ int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* ar
   while (PLANE % 32 != 3) ++PLANE;
   size_t lds = (((size_t)Ci * PLANE + 3) & ~(size_t)3) * 4 + (size_t)Wp * Co * 5;
   if (lds < (size_t)(4 * 32 + 4) * Co * 4) lds = (size_t)(4 * 32 + 4) * Co * 4;   // the end-of-kernel combine area
-  int blocks = B * Hp < kC0Blocks ? B * Hp : kC0Blocks;
+  int per_cu = (int)((160 * 1024) / lds);            // resident workgroups per CU by LDS (wide images need > 53 KB)
+  if (per_cu > 3) per_cu = 3;
+  if (per_cu < 1) per_cu = 1;
+  int blocks = 256 * per_cu;
+  if (blocks > B * Hp) blocks = B * Hp;
   float* slab = workspace;
   float* bias_slab = workspace + (int64_t)kC0Blocks * 32 * Co;
   hipStream_t s = (hipStream_t)stream;
-  C0_DISPATCH(Ci, Co / 32, hipLaunchKernelGGL((conv0_wgrad_kernel<kCI, kTN>), dim3(blocks), dim3(256), lds, s, x_nchw,
-                                              dpooled, argmax, slab, bias_slab, B, H, W, Hp, Wp, RS, PLANE));
+  C0_DISPATCH(Ci, Co / 32, {
+    auto kern = conv0_wgrad_kernel<kCI, kTN>;
+    int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad)");
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, dpooled, argmax, slab, bias_slab, B, H, W, Hp, Wp,
+                       RS, PLANE);
+  });
   int rc = check_hip(hipGetLastError(), "conv0_wgrad launch");
   if (rc) return rc;
   hipLaunchKernelGGL(conv0_wgrad_reduce_kernel, dim3(9 * Ci + 1), dim3(256), 0, s, slab, bias_slab, dw, dbias,

@@ -61,8 +61,8 @@ static WgradPlanB plan_wgrad_bf16(const ConvGeom& g) {
   p.ks_per_split = (p.nk + splits - 1) / splits;
   p.splits = (p.nk + p.ks_per_split - 1) / p.ks_per_split;
   const int64_t windows = (int64_t)g.B * g.Hp * g.Wp;
-  int64_t parts = (windows + 255) / 256;
-  if (parts > 256) parts = 256;
+  int64_t parts = (windows + 63) / 64;
+  if (parts > 2048) parts = 2048;
   p.bias_per = (windows + parts - 1) / parts;
   p.bias_parts = (int)((windows + p.bias_per - 1) / p.bias_per);
   return p;
@@ -163,6 +163,7 @@ int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* ar
                            int64_t workspace_bytes, int tag, vqa_stream_t stream) {
   VQA_REQUIRE(x && dpooled && argmax && dw && dbias && workspace && B > 0, "vqa_conv3x3_wgrad_bf16: null pointer");
   VQA_REQUIRE(Ci >= 1 && Ci <= CiP, "vqa_conv3x3_wgrad_bf16: Ci=%d CiP=%d", Ci, CiP);
+  VQA_REQUIRE(Co % 8 == 0 && Co <= 2048, "vqa_conv3x3_wgrad_bf16: Co=%d must be a multiple of 8, at most 2048", Co);
   const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
   VQA_REQUIRE(chunk > 0, "vqa_conv3x3_wgrad_bf16: one %dx%dx%d image reaches 4 GiB", H, W, CiP);
   const int64_t need = vqa_conv3x3_wgrad_bf16_workspace_bytes(B, H, W, CiP, Co, stride);
@@ -203,7 +204,7 @@ int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* ar
                        workspace + (int64_t)done * KI * Co, p.tiles_m, p.tiles_n, p.nk, p.ks_per_split);
     rc = check_hip(hipGetLastError(), "conv_wgrad_bf16 launch");
     if (rc) return rc;
-    hipLaunchKernelGGL(conv_bias_grad_bf16_kernel, dim3((Co + 63) / 64, p.bias_parts), dim3(256), 0, s,
+    hipLaunchKernelGGL(conv_bias_grad_bf16_kernel, dim3(p.bias_parts), dim3(256), (size_t)(256 / (Co / 8)) * Co * 4, s,
                        reinterpret_cast<const uint16_t*>(dpc), argmax + po, bias_slab0 + (int64_t)bdone * Co,
                        (int64_t)g.B * g.Hp * g.Wp, Co, p.bias_per);
     rc = check_hip(hipGetLastError(), "conv_bias_grad_bf16 launch");

@@ -653,6 +653,8 @@ using namespace vqa;
 extern "C" {
 
 int vqa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa_stream_t stream) {
+  set_launch_tag(n >= (1 << 22) ? 1 : 0);       // 1 = a large tensor (the attention dropout on v), 0 = the small sites
+  ProfScope prof(VQA_K_DROPOUT, (hipStream_t)stream);
   VQA_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f, "vqa_dropout: bad args");
   if (n == 0) return VQA_OK;
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, x, y, n, p, KEEP(p), seed);
@@ -661,6 +663,8 @@ int vqa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa
 
 int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p, uint64_t seed,
                    vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_L2NORM_FWD, (hipStream_t)stream);
   VQA_REQUIRE(pooled && vn && norm && rows > 0 && C > 0 && C % 4 == 0, "vqa_l2norm_fwd: bad args (C=%d)", C);
   hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, pooled, vn, norm, rows, C, p,
                      KEEP(p), seed);
@@ -669,6 +673,8 @@ int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, in
 
 int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, float* dpooled, int64_t rows, int C,
                    float p, uint64_t seed, vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_L2NORM_BWD, (hipStream_t)stream);
   VQA_REQUIRE(dvn && vn && norm && dpooled && rows > 0 && C % 4 == 0, "vqa_l2norm_bwd: bad args");
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
                      C, p, KEEP(p), seed);
@@ -718,6 +724,8 @@ int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out,
 
 int vqa_att_score_fwd(const float* xs, const float* wx, int wx_ld, const float* bx, float* score, int B, int P, int mid,
                       int G, float p, uint64_t seed, const float* qcat, vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_ATT_SCORE_FWD, (hipStream_t)stream);
   VQA_REQUIRE(xs && wx && bx && score && mid % 4 == 0 && wx_ld % 4 == 0 && wx_ld >= (qcat ? 2 * mid : mid),
               "vqa_att_score_fwd: bad args");
   const int64_t M = (int64_t)B * P;
@@ -734,6 +742,8 @@ int vqa_att_row_splits(int P) {
 int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, float* xs_inout, float* dwx_part,
                       float* dq_part, int B, int P, int mid, int G, float p, uint64_t seed, int mode,
                       const float* vprime, const float* qp, vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_ATT_SCORE_BWD, (hipStream_t)stream);
   VQA_REQUIRE(dscore && wx && xs_inout && dwx_part && dq_part && mid % 4 == 0 && wx_ld % 4 == 0,
               "vqa_att_score_bwd: bad args");
   VQA_REQUIRE(mode >= 0 && mode <= 2 && (mode != 1 || (vprime && qp)) && (mode != 2 || qp) &&
@@ -747,6 +757,8 @@ int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, float* xs
 
 int vqa_att_apply_fwd(const float* score, const float* vn, float* probs, float* out, int64_t out_ld, int B, int P,
                       int C, int G, vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_ATT_APPLY_FWD, (hipStream_t)stream);
   VQA_REQUIRE(score && vn && probs && out, "vqa_att_apply_fwd: null pointer");
   const size_t lds = ((size_t)G * P + 16 + 4 * G * 64) * 4;
   VQA_REQUIRE(lds <= 64 * 1024, "vqa_att_apply_fwd: G*P=%d too large for LDS", G * P);
@@ -757,6 +769,8 @@ int vqa_att_apply_fwd(const float* score, const float* vn, float* probs, float* 
 
 int vqa_att_apply_bwd(const float* dout, int64_t dout_ld, const float* probs, const float* vn, float* dscore,
                       float* dvn, float* dscore_rowsum, int B, int P, int C, int G, vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_ATT_APPLY_BWD, (hipStream_t)stream);
   VQA_REQUIRE(dout && probs && vn && dscore && dvn && C % 4 == 0 && dout_ld % 4 == 0, "vqa_att_apply_bwd: bad args");
   const int64_t M = (int64_t)B * P;
   DISPATCH_G(G, hipLaunchKernelGGL(att_apply_bwd_rows_kernel<kG>, dim3(grid_for(M, 4)), dim3(256), 0, STREAM, dout,
@@ -770,6 +784,8 @@ int vqa_att_apply_bwd(const float* dout, int64_t dout_ld, const float* probs, co
 int vqa_softce_fwd_bwd(const float* logits, int64_t ld, const int64_t* a_idx, const int64_t* a_val, int kmax, int B,
                        int A, float inv_batch, float* loss_rows, float* score_rows, float* dlogits, int64_t dld,
                        vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_SOFTCE, (hipStream_t)stream);
   VQA_REQUIRE(logits && a_idx && a_val && loss_rows && score_rows && B > 0 && A > 0 && kmax >= 0,
               "vqa_softce_fwd_bwd: bad args");
   hipLaunchKernelGGL(softce_kernel, dim3(B), dim3(256), 0, STREAM, logits, ld, a_idx, a_val, kmax, A, inv_batch,
@@ -829,6 +845,8 @@ int vqa_scale_by(float* x, int64_t n, const float* scalar, vqa_stream_t stream) 
 
 int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
              float beta2, float eps, int step, float grad_scale, vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_ADAM, (hipStream_t)stream);
   VQA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "vqa_adam: bad args");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)((double)lr / bc1);

@@ -66,16 +66,19 @@ const Knobs& knobs() {
 
 // ------------------------------------------------------------------ profiling hook
 static std::mutex g_prof_mu;
-static int g_prof_id = -1, g_prof_tag = -1;
+static uint32_t g_prof_mask = 0;
+static int g_prof_tag = -1;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
 static std::vector<std::pair<int, int>> g_prof_key;   // (family, tag) of each recorded event pair
 static thread_local int g_launch_tag = -1;
 void set_launch_tag(int tag) { g_launch_tag = tag; }
 
 ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(false) {
-  if (g_prof_id < 0) return;
+  if (g_prof_mask == 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if ((g_prof_id != id && g_prof_id != VQA_K_COUNT) || (g_prof_tag >= 0 && g_prof_tag != g_launch_tag)) return;
+  if (!((g_prof_mask >> id) & 1u) || (g_prof_tag >= 0 && g_prof_tag != g_launch_tag)) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;       // never inside a stream capture
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
   hipEventRecord(a, s);
@@ -263,14 +266,19 @@ int vqa_reload_knobs(void) {
   return VQA_OK;
 }
 
-int vqa_prof_arm(int kernel_id, int tag) {
+int vqa_prof_arm_mask(uint32_t mask, int tag) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& e : g_prof_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   g_prof_ev.clear();
   g_prof_key.clear();
-  g_prof_id = kernel_id;
+  g_prof_mask = mask;
   g_prof_tag = tag;
   return VQA_OK;
+}
+
+int vqa_prof_arm(int kernel_id, int tag) {
+  const uint32_t all = (1u << VQA_K_COUNT) - 1u;
+  return vqa_prof_arm_mask(kernel_id < 0 ? 0u : (kernel_id >= VQA_K_COUNT ? all : (1u << kernel_id)), tag);
 }
 
 int vqa_prof_read_groups(int* ids, int* tags, int* launches, float* total_ms, int cap) {

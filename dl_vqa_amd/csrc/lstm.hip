@@ -21,6 +21,7 @@
 //                  differentiated: it turns dh_{prev} (+ the pass-through of finished samples) straight into that
 //                  step's dgates, which is the A operand of the next launch.  One launch per step replaces
 //                  lstm_cell_bwd + split-K GEMM + splitk_reduce.
+#include <array>
 #include <map>
 #include <mutex>
 
@@ -458,8 +459,10 @@ static std::mutex g_graph_mu;
 static std::map<GraphKey, GraphEntry> g_graphs;
 static uint64_t g_graph_clock = 0;
 static int g_graph_hits = 0, g_graph_builds = 0, g_graph_eager = 0;
-static unsigned g_graph_recent = 0;          // bit history of the last calls: 1 = had to build
+// (kind, ndir, B, T, H) -> consecutive calls of that shape that found no cached graph (their buffers had moved)
+static std::map<std::array<int, 5>, int> g_graph_miss_streak;
 constexpr size_t kGraphCap = 32;
+constexpr int kMissStreakLimit = 8;
 
 static int build_graph(int kind, const SeqArgs& a, const SeqPlan& p, GraphEntry* out) {
   hipGraph_t g;
@@ -513,11 +516,13 @@ static int run_sequence(int kind, const SeqArgs& a, int use_graph, hipStream_t s
     key.a = a;
     std::lock_guard<std::mutex> lk(g_graph_mu);
     auto it = g_graphs.find(key);
+    int& streak = g_graph_miss_streak[std::array<int, 5>{kind, a.ndir, a.B, a.T, a.H}];
     if (it == g_graphs.end()) {
-      // buffers that change every call would rebuild a graph every call: after 12 builds in the last 16 calls this
-      // call falls back to plain launches (the history keeps sliding, so a settled loop returns to graphs)
-      if (__builtin_popcount(g_graph_recent & 0xffffu) >= 12) {
-        g_graph_recent <<= 1;
+      // a caller whose buffers move on every call would build a graph per call: after 8 consecutive misses of one
+      // shape its calls are served by plain launches; every 64th of them tries a graph again (a loop that settles
+      // later returns to replays)
+      ++streak;
+      if (streak > kMissStreakLimit && (streak & 63) != 0) {
         use_graph = 0;
         ++g_graph_eager;
       } else {
@@ -532,11 +537,10 @@ static int run_sequence(int kind, const SeqArgs& a, int use_graph, hipStream_t s
           g_graphs.erase(old);
         }
         it = g_graphs.emplace(key, e).first;
-        g_graph_recent = (g_graph_recent << 1) | 1u;
         ++g_graph_builds;
       }
     } else {
-      g_graph_recent <<= 1;
+      streak = 0;
       ++g_graph_hits;
     }
     if (use_graph) {
@@ -597,6 +601,8 @@ int vqa_lstm_seq_fwd(const vqa_lstm_dir_t* dirs, int ndir, const int64_t* q_len,
   SeqArgs a;
   int rc = make_args("vqa_lstm_seq_fwd", dirs, ndir, q_len, B, T, H, cf_ld, false, &a);
   if (rc) return rc;
+  set_launch_tag(0);
+  ProfScope prof(VQA_K_LSTM_SEQ, (hipStream_t)stream);
   return run_sequence(0, a, use_graph, (hipStream_t)stream);
 }
 
@@ -605,6 +611,8 @@ int vqa_lstm_seq_bwd(const vqa_lstm_dir_t* dirs, int ndir, const int64_t* q_len,
   SeqArgs a;
   int rc = make_args("vqa_lstm_seq_bwd", dirs, ndir, q_len, B, T, H, 0, true, &a);
   if (rc) return rc;
+  set_launch_tag(1);
+  ProfScope prof(VQA_K_LSTM_SEQ, (hipStream_t)stream);
   return run_sequence(1, a, use_graph, (hipStream_t)stream);
 }
 

@@ -86,6 +86,8 @@ class Engine:
             self._sides = {}
         key = str(dev)
         if key not in self._sides:
+            # (a high-priority side stream measured no difference: 27.03 / 27.05 ms per step, 115.4 / 115.6 at the
+            # stress shape)
             self._sides[key] = [torch.cuda.Stream(device=dev) for _ in range(2)]
         return self._sides[key]
 

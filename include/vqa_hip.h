@@ -50,12 +50,25 @@ enum {
   VQA_K_CONV_FWD = 1,
   VQA_K_CONV_DGRAD = 2,
   VQA_K_CONV_WGRAD = 3,
-  VQA_K_COUNT = 4
+  /* HBM-bound stages (bench.py reports GB/s against the 8 TB/s HBM3E peak for these) */
+  VQA_K_L2NORM_FWD = 4,
+  VQA_K_L2NORM_BWD = 5,
+  VQA_K_ATT_SCORE_FWD = 6,
+  VQA_K_ATT_SCORE_BWD = 7,
+  VQA_K_ATT_APPLY_FWD = 8,
+  VQA_K_ATT_APPLY_BWD = 9,
+  VQA_K_ADAM = 10,
+  VQA_K_SOFTCE = 11,
+  VQA_K_DROPOUT = 12,
+  VQA_K_LSTM_SEQ = 13, /* one whole vqa_lstm_seq_fwd / _bwd call (T launches or one graph replay) */
+  VQA_K_COUNT = 14
 };
 /* Arm event bracketing for kernel family `kernel_id` whose launch tag equals `tag`
  * (tag < 0: any). kernel_id == VQA_K_COUNT arms every family; kernel_id < 0 disarms.
  * Resets the accumulated numbers. */
 int vqa_prof_arm(int kernel_id, int tag);
+/* The same for a SET of families: bit k of `mask` arms family k (mask 0 disarms). */
+int vqa_prof_arm_mask(uint32_t mask, int tag);
 /* Synchronise the recorded events; returns launches counted and their total device time. */
 int vqa_prof_read(int* launches, float* total_ms);
 /* Per (family, tag) totals of the recorded events: fills up to `cap` entries of ids / tags / launches /

@@ -556,7 +556,7 @@ def test_dropout_statistics_and_determinism():
 
 # ----------------------------------------------------------------------------- first conv block (dedicated path)
 @pytest.mark.parametrize("B,Ci,H,W,Co", [(2, 3, 20, 24, 32), (3, 3, 31, 28, 64), (2, 2, 16, 16, 64), (1, 1, 9, 12, 32),
-                                         (2, 3, 224, 224, 64)])
+                                         (2, 3, 224, 224, 64), (1, 3, 62, 448, 64)])   # 448 wide: > 64 KB of LDS (configs[3])
 def test_conv0_dedicated_fwd_wgrad(B, Ci, H, W, Co):
     ops = _ops()
     assert ops.conv0_supported(Ci, H, W, Co, 1)

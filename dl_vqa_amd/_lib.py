@@ -39,7 +39,8 @@ PROTOTYPES = {
     "vqa_conv0_wgrad_workspace_bytes": (i64, [i32]),
     "vqa_conv0_wgrad": (i32, [f32p, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, vp]),
     "vqa_dropout": (i32, [f32p, f32p, i64, f32, u64, vp]),
-    "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp]),
+    "vqa_dropout_add": (i32, [f32p, f32p, i64, f32, u64, vp]),
+    "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp, i32, f32, u64, vp]),
     "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, f32, u64, vp]),
     "vqa_embed_tanh_fwd": (i32, [i64p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp, vp]),
     "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),

@@ -6,6 +6,12 @@
 
 namespace vqa {
 
+__device__ __forceinline__ uint32_t f2bf16_pair(float lo, float hi) {      // round to nearest even (v_cvt_pk_bf16_f32)
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const bf2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
 static inline int grid_for(int64_t n, int per_block, int cap = 8192) {
   int64_t b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -19,10 +25,28 @@ __global__ void dropout_kernel(const float* x, float* y, int64_t n, float p, flo
     y[i] = x[i] * drop_scale(seed, (uint64_t)i, p, inv_keep);
 }
 
+// y += dropout(x): 4 elements per thread and iteration
+__global__ void dropout_add_kernel(const float* x, float* y, int64_t n, float p, float inv_keep, uint64_t seed) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[i];
+    float4 b = reinterpret_cast<float4*>(y)[i];
+    b.x += a.x * drop_scale(seed, (uint64_t)(4 * i), p, inv_keep); b.y += a.y * drop_scale(seed, (uint64_t)(4 * i + 1), p, inv_keep);
+    b.z += a.z * drop_scale(seed, (uint64_t)(4 * i + 2), p, inv_keep); b.w += a.w * drop_scale(seed, (uint64_t)(4 * i + 3), p, inv_keep);
+    reinterpret_cast<float4*>(y)[i] = b;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) {
+    const int64_t i = 4 * n4 + threadIdx.x;
+    y[i] += x[i] * drop_scale(seed, (uint64_t)i, p, inv_keep);
+  }
+}
+
 // ------------------------------------------------------------------ L2 norm (+ image dropout)
 // one wave per row of C floats
+// vdrop (optional, fp32 or bf16 by VB): dropout_{p2, seed2}(vn) written in the same pass
+template <bool VB>
 __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p,
-                                  float inv_keep, uint64_t seed) {
+                                  float inv_keep, uint64_t seed, void* vdrop, float p2, float inv_keep2, uint64_t seed2) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -51,7 +75,23 @@ __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, i
         u.x *= drop_scale(seed, e, p, inv_keep); u.y *= drop_scale(seed, e + 1, p, inv_keep);
         u.z *= drop_scale(seed, e + 2, p, inv_keep); u.w *= drop_scale(seed, e + 3, p, inv_keep);
       }
-      dst[c] = make_float4(u.x * inv, u.y * inv, u.z * inv, u.w * inv);
+      const float4 o = make_float4(u.x * inv, u.y * inv, u.z * inv, u.w * inv);
+      dst[c] = o;
+      if (vdrop) {
+        const uint64_t e = (uint64_t)r * C + 4 * c;
+        float4 d = o;
+        if (p2 > 0.f) {
+          d.x *= drop_scale(seed2, e, p2, inv_keep2); d.y *= drop_scale(seed2, e + 1, p2, inv_keep2);
+          d.z *= drop_scale(seed2, e + 2, p2, inv_keep2); d.w *= drop_scale(seed2, e + 3, p2, inv_keep2);
+        }
+        if (VB) {
+          uint2 w;
+          w.x = f2bf16_pair(d.x, d.y); w.y = f2bf16_pair(d.z, d.w);
+          reinterpret_cast<uint2*>(static_cast<uint16_t*>(vdrop) + r * C)[c] = w;
+        } else {
+          reinterpret_cast<float4*>(static_cast<float*>(vdrop) + r * C)[c] = d;
+        }
+      }
     }
   }
 }
@@ -661,13 +701,27 @@ int vqa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa
   return check_hip(hipGetLastError(), "dropout launch");
 }
 
+int vqa_dropout_add(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa_stream_t stream) {
+  set_launch_tag(n >= (1 << 22) ? 1 : 0);
+  ProfScope prof(VQA_K_DROPOUT, (hipStream_t)stream);
+  VQA_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "vqa_dropout_add: bad args");
+  VQA_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "vqa_dropout_add: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, STREAM, x, y, n, p, KEEP(p), seed);
+  return check_hip(hipGetLastError(), "dropout_add launch");
+}
+
 int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p, uint64_t seed,
-                   vqa_stream_t stream) {
+                   void* vdrop, int vdrop_is_bf16, float p2, uint64_t seed2, vqa_stream_t stream) {
   set_launch_tag(-1);
   ProfScope prof(VQA_K_L2NORM_FWD, (hipStream_t)stream);
   VQA_REQUIRE(pooled && vn && norm && rows > 0 && C > 0 && C % 4 == 0, "vqa_l2norm_fwd: bad args (C=%d)", C);
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, pooled, vn, norm, rows, C, p,
-                     KEEP(p), seed);
+  VQA_REQUIRE(p2 >= 0.f && p2 < 1.f, "vqa_l2norm_fwd: p2 must be in [0, 1)");
+  if (vdrop && vdrop_is_bf16)
+    hipLaunchKernelGGL(l2norm_fwd_kernel<true>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, pooled, vn, norm, rows, C, p,
+                       KEEP(p), seed, vdrop, p2, KEEP(p2), seed2);
+  else
+    hipLaunchKernelGGL(l2norm_fwd_kernel<false>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, pooled, vn, norm, rows, C, p,
+                       KEEP(p), seed, vdrop, p2, KEEP(p2), seed2);
   return check_hip(hipGetLastError(), "l2norm_fwd launch");
 }
 

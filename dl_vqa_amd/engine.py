@@ -228,25 +228,30 @@ class Engine:
         Pn = pooled.shape[1] * pooled.shape[2]
         # ---- image dropout + L2 normalisation over channels (model.py:84,56)
         p_img = self.p_image if tr else 0.0
-        vn, norm = ops.l2norm_fwd(pooled, p_img, sd(SITE_IMAGE))
+        # attention.drop(v) (model.py:185) is written by the same pass as a second output: the v_conv operand, as
+        # bf16 on the bf16 path
+        p_att = self.p_att if tr else 0.0
+        v_in = v16 = None
+        if self.bf16:
+            vn, norm, v16 = ops.l2norm_fwd(pooled, p_img, sd(SITE_IMAGE), drop2=(p_att, sd(SITE_ATT_V), torch.bfloat16))
+        elif p_att > 0:
+            vn, norm, v_in = ops.l2norm_fwd(pooled, p_img, sd(SITE_IMAGE), drop2=(p_att, sd(SITE_ATT_V), torch.float32))
+        else:
+            vn, norm = ops.l2norm_fwd(pooled, p_img, sd(SITE_IMAGE))
+            v_in = vn
         main.wait_event(text_done)
 
         qf = combined[:, GC:]
 
         # ---- attention (model.py:183-195): v' = v_conv(drop(v)), q' = q_lin(drop(q)), x = relu(v' + q')
-        p_att = self.p_att if tr else 0.0
-        v16 = wv16 = None
-        if self.bf16:
-            v16 = ops.dropout_to_bf16(vn, p_att, sd(SITE_ATT_V))      # attention.drop(v) fused with the bf16 copy
-            wv16 = ops.to_bf16(P["attention.v_conv.weight"].view(mid, C))
+        wv16 = ops.to_bf16(P["attention.v_conv.weight"].view(mid, C)) if self.bf16 else None
         if p_att > 0:
-            v_in = None if self.bf16 else ops.dropout(vn, p_att, sd(SITE_ATT_V))
             q_in = new(B, Q)
             ops.add2d(qf, Dc, None, 0, q_in, Q, B, Q)
             ops.dropout(q_in, p_att, sd(SITE_ATT_Q), out=q_in)
             ld_q = Q
         else:
-            v_in, q_in, ld_q = vn, qf, Dc
+            q_in, ld_q = qf, Dc
         qp = new(B, mid)
         ops.gemm(q_in, P["attention.q_lin.weight"], qp, B, mid, Q, lda=ld_q, bias1=P["attention.q_lin.bias"], tag=20)
         # x = relu(v' + q') | relu(v' * q') | relu(cat[v', q'])  (model.py:188-193); v' itself is only kept for
@@ -343,22 +348,20 @@ class Engine:
             dx16 = ops.to_bf16(dxpre)
             ops.gemm_bf16(dx16, ctx.v16.view(B * Pn, C), Gr["attention.v_conv.weight"].view(mid, C), mid, C, B * Pn,
                           transA=True, transB=False, lda=mid, ldb=C, tag=44)
-            if ctx.p_att > 0:
+            if ctx.p_att > 0:       # dvn += dropout-mask * (dx' . Wv): one pass joins the two branches
                 dv_in = new(B * Pn, C)
                 ops.gemm_bf16(dx16, ctx.wv16, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
-                ops.dropout(dv_in, ctx.p_att, sd(SITE_ATT_V), out=dv_in)
-                ops.add(dvn, dv_in, dvn)
+                ops.dropout_add(dv_in, dvn, ctx.p_att, sd(SITE_ATT_V))
             else:
                 ops.gemm_bf16(dx16, ctx.wv16, dvn.view(B * Pn, C), B * Pn, C, mid, transB=False, lda=mid, ldb=C,
                               accumulate=True, tag=45)
         else:
             ops.gemm(dxpre, ctx.v_in, Gr["attention.v_conv.weight"], mid, C, B * Pn, transA=True, transB=False, lda=mid,
                      ldb=C, tag=44)
-            if ctx.p_att > 0:
+            if ctx.p_att > 0:       # dvn += dropout-mask * (dx' . Wv): one pass joins the two branches
                 dv_in = new(B * Pn, C)
                 ops.gemm(dxpre, wv, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
-                ops.dropout(dv_in, ctx.p_att, sd(SITE_ATT_V), out=dv_in)
-                ops.add(dvn, dv_in, dvn)
+                ops.dropout_add(dv_in, dvn, ctx.p_att, sd(SITE_ATT_V))
             else:
                 ops.gemm(dxpre, wv, dvn, B * Pn, C, mid, transB=False, lda=mid, ldb=C, accumulate=True, tag=45)
         ops.gemm(dqp, ctx.q_in, Gr["attention.q_lin.weight"], mid, Q, B, transA=True, transB=False, lda=mid,

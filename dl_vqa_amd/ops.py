@@ -127,13 +127,26 @@ def dropout(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = 
     return y
 
 
-def l2norm_fwd(pooled: torch.Tensor, p: float, seed: int):
+def dropout_add(x: torch.Tensor, y: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    """y += dropout_{p, seed}(x) in one pass."""
+    call("vqa_dropout_add", ptr(x), ptr(y), x.numel(), p, seed, stream())
+    return y
+
+
+def l2norm_fwd(pooled: torch.Tensor, p: float, seed: int, drop2=None):
+    """drop2 = (p2, seed2, dtype): also return dropout_{p2, seed2}(vn) in fp32 or bf16 (written in the same pass)."""
     C = pooled.shape[-1]
     rows = pooled.numel() // C
     vn = torch.empty_like(pooled)
     norm = torch.empty(rows, dtype=torch.float32, device=pooled.device)
-    call("vqa_l2norm_fwd", ptr(pooled), ptr(vn), ptr(norm), rows, C, p, seed, stream())
-    return vn, norm
+    if drop2 is None:
+        call("vqa_l2norm_fwd", ptr(pooled), ptr(vn), ptr(norm), rows, C, p, seed, None, 0, 0.0, 0, stream())
+        return vn, norm
+    p2, seed2, dtype = drop2
+    vd = torch.empty(pooled.shape, dtype=dtype, device=pooled.device)
+    call("vqa_l2norm_fwd", ptr(pooled), ptr(vn), ptr(norm), rows, C, p, seed, ptr(vd), int(dtype == torch.bfloat16), p2, seed2,
+         stream())
+    return vn, norm, vd
 
 
 def l2norm_bwd(dvn, vn, norm, p: float, seed: int, out=None):

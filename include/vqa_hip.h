@@ -128,11 +128,16 @@ int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* ar
  * y = x * keep(seed, i) / (1-p); keep() is a counter-based hash, so backward calls the same
  * function on the gradient. In-place allowed. */
 int vqa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa_stream_t stream);
+/* y += x * keep(seed, i) / (1-p): the backward of a dropout whose gradient joins another one (attention.drop on v:
+ * d loss / d v = dropout-mask * d loss / d v_in + the weighted-sum branch, models/model.py:185,62) in ONE pass. */
+int vqa_dropout_add(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa_stream_t stream);
 
 /* ---- L2 normalisation over channels (models/model.py:56), fused with image.drop (model.py:84) -
- * u = dropout(pooled); norm = ||u||_2 per row; vn = u / (norm + 1e-12).  rows = B*P, C channels. */
+ * u = dropout(pooled); norm = ||u||_2 per row; vn = u / (norm + 1e-12).  rows = B*P, C channels.
+ * vdrop (optional): a second output dropout_{p2, seed2}(vn), fp32 or bf16 -- attention.drop applied to v
+ * (models/model.py:185), i.e. the v_conv operand, written in the same pass. */
 int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p,
-                   uint64_t seed, vqa_stream_t stream);
+                   uint64_t seed, void* vdrop, int vdrop_is_bf16, float p2, uint64_t seed2, vqa_stream_t stream);
 int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, float* dpooled, int64_t rows,
                    int C, float p, uint64_t seed, vqa_stream_t stream);
 

@@ -242,6 +242,27 @@ def test_l2norm_fwd_bwd():
     assert bool(torch.isfinite(du).all())
 
 
+def test_l2norm_second_output_and_dropout_add():
+    """The attention dropout on v (models/model.py:185) is fused twice: forward as a second output of the L2-norm
+    pass (fp32, or bf16 on the bf16 path), backward as y += dropout(x) in one pass (vqa_dropout_add).  Both must equal
+    the stand-alone vqa_dropout."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    u = torch.randn(300, 64, generator=g).to(DEV)
+    vn, norm = ops.l2norm_fwd(u, 0.0, 0)
+    ref = ops.dropout(vn, 0.3, 777)
+    vn2, _, vd = ops.l2norm_fwd(u, 0.0, 0, drop2=(0.3, 777, torch.float32))
+    vn3, _, vb = ops.l2norm_fwd(u, 0.0, 0, drop2=(0.3, 777, torch.bfloat16))
+    torch.cuda.synchronize()
+    assert torch.equal(vn, vn2) and torch.equal(vn, vn3) and torch.equal(vd, ref) and torch.equal(vb, ref.to(torch.bfloat16))
+    g2 = torch.randn(300 * 64 + 3, generator=g).to(DEV)            # + a tail that is not a multiple of 4
+    acc = torch.randn(300 * 64 + 3, generator=g).to(DEV)
+    want = acc + ops.dropout(g2, 0.3, 4242)
+    ops.dropout_add(g2, acc, 0.3, 4242)
+    torch.cuda.synchronize()
+    assert float((acc - want).abs().max()) <= 1e-6 * float(want.abs().max())      # fused multiply-add vs two roundings
+
+
 def test_embed_tanh_fwd_bwd():
     ops = _ops()
     g = torch.Generator().manual_seed(4)

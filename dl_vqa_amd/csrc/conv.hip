@@ -54,7 +54,10 @@ using Cfg256x128L8 = TileCfg<256, 128, 4, 2, 8>;
 using Cfg256x64L8 = TileCfg<256, 64, 4, 2, 8>;
 // dgrad with CiP <= 64 (conv1): a K-step is only 32 MFMAs per wave, so the loaders are the long pole; with 8
 // loader waves (768 threads, 74 VGPRs: two workgroups = 6 waves per SIMD) 70.6 -> 73.0 % on the same box
-using Cfg128x64L8 = TileCfg<128, 64, 2, 2, 8, 2>;
+#ifndef VQA_DGRAD_PF
+#define VQA_DGRAD_PF 2
+#endif
+using Cfg128x64L8 = TileCfg<128, 64, 2, 2, 8, VQA_DGRAD_PF>;
 
 template <class Cfg, bool U>
 static int launch_fwd(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* amax,

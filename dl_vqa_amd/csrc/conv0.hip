@@ -119,6 +119,103 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------ forward on bf16 MFMA (bf16 path, configs[3])
+// Same patch staging (fp32, planar), but the 27 taps (padded to 32) are two v_mfma_f32_32x32x16_bf16 k-steps: a lane
+// gathers its 2 x 8 taps from the patch, rounds them to bf16 (the image is rounded where it is consumed, as the weights
+// are) and issues 2 x TN MFMAs per 32-pixel tile instead of 14 x TN fp32 ones -- the kernel becomes store-bound.
+template <int CI, int TN>
+__global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, uint16_t* pooled16,
+                                                             uint8_t* amax, int H, int W, int Hp, int Wp, int RS) {
+  extern __shared__ __attribute__((aligned(16))) float patch[];
+  constexpr int K = 9 * CI, Co = 32 * TN;
+  static_assert(K <= 32, "two 16-deep k-steps cover at most 32 taps");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y, py0 = C0_FR * blockIdx.x;
+  const int nwr = min(C0_FR, Hp - py0);
+  const int y0 = 2 * py0, nrows = 2 * nwr + 2;
+  const int plane = C0_PR * RS;
+  for (int r = wave; r < CI * C0_PR; r += 4) {
+    const int c = r / C0_PR, rr = r - c * C0_PR;
+    const float* src = x + ((int64_t)(b * CI + c) * H + y0 + rr) * W;
+    float* dst = patch + c * plane + rr * RS;
+    for (int c4 = lane; c4 < W / 4; c4 += 64) {
+      const float4 v = rr < nrows ? *reinterpret_cast<const float4*>(src + 4 * c4) : f4zero();
+      dst[4 * c4] = v.x; dst[4 * c4 + 1] = v.y; dst[4 * c4 + 2] = v.z; dst[4 * c4 + 3] = v.w;
+    }
+  }
+  // weights as bf16 B fragments (element e of k-step ks: tap k = 16 ks + 8 h + e), tap offsets as per-lane constants
+  bf16x8 bw[2][TN];
+  int koff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    float wv[TN][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * ks + 8 * h + e;
+      const bool kok = k < K;
+      const int kk = kok ? k : 0;
+      const int c = kk / 9, t = kk - 9 * c, ky = t / 3, kx = t - 3 * ky;
+      koff[ks][e] = c * plane + ky * RS + kx;            // taps >= K read tap 0 (finite) against a zero weight
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wv[j][e] = kok ? w[(int64_t)(32 * j + l31) * K + kk] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const uint4 pk = make_uint4(pack_bf16x2(wv[j][0], wv[j][1]), pack_bf16x2(wv[j][2], wv[j][3]),
+                                  pack_bf16x2(wv[j][4], wv[j][5]), pack_bf16x2(wv[j][6], wv[j][7]));
+      bw[ks][j] = __builtin_bit_cast(bf16x8, pk);
+    }
+  }
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[j] = bias[32 * j + l31];
+  __syncthreads();
+
+  const int nwin = nwr * Wp, ntiles = (nwin + 7) / 8;
+  const int64_t o0 = (int64_t)(b * Hp + py0) * Wp * Co;
+  const __amdgpu_buffer_rsrc_t rp = buf_rsrc(pooled16 + o0), ra = buf_rsrc(amax + o0);
+  for (int t = wave; t < ntiles; t += 4) {
+    int wdx = 8 * t + (l31 >> 2);
+    if (wdx >= nwin) wdx = 0;
+    const int wr = (wdx >= Wp ? 1 : 0) + (wdx >= 2 * Wp ? 1 : 0) + (wdx >= 3 * Wp ? 1 : 0);
+    const int px = wdx - __mul24(wr, Wp), j4 = l31 & 3;
+    const float* ap = patch + __mul24(2 * wr + (j4 >> 1), RS) + 2 * px + (j4 & 1);
+    f32x16 acc[TN];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ap[koff[ks][e]];
+      const uint4 pk = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                  pack_bf16x2(v[6], v[7]));
+      const bf16x8 a = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks][j], ks == 0 ? zero : acc[j], 0, 0, 0);
+    }
+    const bool inner = 8 * t + 8 <= nwin;
+    const uint32_t vl = (uint32_t)__mul24(8 * t + h, Co) + (uint32_t)l31;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bool ok = inner || 8 * t + 2 * g + h < nwin;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float best = acc[j][4 * g];
+        int a = 0;
+        if (acc[j][4 * g + 1] > best) { best = acc[j][4 * g + 1]; a = 1; }
+        if (acc[j][4 * g + 2] > best) { best = acc[j][4 * g + 2]; a = 2; }
+        if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
+        best += bv[j];
+        const uint32_t so = (uint32_t)(2 * g * Co + 32 * j);
+        buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl : BUF_OOB, 2u * so);
+        buf_store1(ra, best > 0.f ? (uint8_t)a : (uint8_t)4, ok ? vl : BUF_OOB, so);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad
 // persistent grid; 256 threads; LDS = CI*PLANE (x patch, 4 rows) + Wp*Co (dP row) floats + Wp*Co bytes (arg-max row)
 template <int CI, int TN>
@@ -272,7 +369,18 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
     if (rc0) return rc0;                                                                                               \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS); \
   })
-  if (pooled_is_bf16) { C0_FWD_LAUNCH(true); } else { C0_FWD_LAUNCH(false); }
+  if (pooled_is_bf16 == 2) {      // bf16 MFMA (image and weights rounded to bf16), bf16 output
+    VQA_REQUIRE(Ci <= 3, "vqa_conv0_relu_pool_fwd: the bf16-MFMA first block needs Ci <= 3");
+    C0_DISPATCH(Ci, Co / 32, {
+      if constexpr (kCI <= 3) {
+        auto kern = conv0_fwd_bf16_kernel<kCI, kTN>;
+        int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd_bf16)");
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, static_cast<uint16_t*>(pooled),
+                           argmax, H, W, Hp, Wp, RS);
+      }
+    });
+  } else if (pooled_is_bf16) { C0_FWD_LAUNCH(true); } else { C0_FWD_LAUNCH(false); }
 #undef C0_FWD_LAUNCH
   return check_hip(hipGetLastError(), "conv0_fwd launch");
 }

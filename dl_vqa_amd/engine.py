@@ -202,7 +202,7 @@ class Engine:
             assert w.shape[0] == self.channels[l + 1]
             if l == 0 and fast0:
                 pooled, am = ops.conv0_fwd(v, w, P["image.conv0.bias"],
-                                           out_dtype=torch.bfloat16 if self.bf16 else torch.float32)
+                                           out_dtype=torch.bfloat16 if self.bf16 else torch.float32, bf16_mfma=self.bf16)
                 acts.append(pooled)
                 idxs.append(am)
                 wds.append(None)

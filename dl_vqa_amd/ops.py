@@ -100,15 +100,16 @@ def conv0_supported(Ci: int, H: int, W: int, Co: int, stride: int) -> bool:
     return bool(_lib.load().vqa_conv0_supported(Ci, H, W, Co, stride))
 
 
-def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype=torch.float32):
-    """First conv block straight from the NCHW image: (pooled NHWC [B,Hp,Wp,Co] fp32 or bf16, argmax uint8)."""
+def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype=torch.float32, bf16_mfma=False):
+    """First conv block straight from the NCHW image: (pooled NHWC [B,Hp,Wp,Co] fp32 or bf16, argmax uint8).
+    bf16_mfma (bf16 output only): image and weights rounded to bf16, bf16 MFMA."""
     B, Ci, H, W = x_nchw.shape
     Co = w.shape[0]
     Hp, Wp = conv_out_hw(H, W, 1)
     pooled = torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x_nchw.device)
     amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x_nchw.device)
-    call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(pooled), int(out_dtype == torch.bfloat16),
-         ptr(amax), B, Ci, H, W, Co, stream())
+    mode = (2 if bf16_mfma else 1) if out_dtype == torch.bfloat16 else 0
+    call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(pooled), mode, ptr(amax), B, Ci, H, W, Co, stream())
     return pooled, amax
 
 

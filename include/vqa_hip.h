@@ -117,7 +117,8 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
  * as vqa_conv3x3_relu_pool_fwd.  vqa_conv0_supported() tells whether a shape takes this path. */
 int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride);
 int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, void* pooled,
-                            int pooled_is_bf16 /* bf16 path: P_0 stored as bf16 */, uint8_t* argmax, int B, int Ci,
+                            int pooled_is_bf16 /* 0: fp32 out; 1: fp32 MFMA, P_0 stored as bf16; 2 (bf16 path):
+                            image and weights rounded to bf16, two 32x32x16 bf16 MFMA k-steps, bf16 out */, uint8_t* argmax, int B, int Ci,
                             int H, int W, int Co, vqa_stream_t stream);
 int64_t vqa_conv0_wgrad_workspace_bytes(int Co);
 int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias,

@@ -60,7 +60,7 @@ def _drop(x: Tensor, masks: Optional[dict], site: str) -> Tensor:
 
 # bf16 path (BASELINE configs[3]): the same oracle with the operands of the re-typed contractions rounded to
 # bfloat16 where the HIP path stores / stages them as bf16 (round to nearest even; products of two bf16 values are
-# exact in fp32, accumulation stays fp32): the activations between conv blocks, the conv weights of blocks >= 1, the
+# exact in fp32, accumulation stays fp32): the image and the activations between conv blocks, the conv weights, the
 # v_conv input and weight; in backward, the gradients the HIP path stores as bf16 (dP of the conv blocks >= 1, dx').
 def rb(x: Tensor) -> Tensor:
     return x.to(torch.bfloat16).to(x.dtype)
@@ -79,6 +79,23 @@ class _RoundFB(torch.autograd.Function):
         return (rb(g) if ctx.bwd else g), None, None
 
 
+class _FirstConvBf16(torch.autograd.Function):
+    """First conv block of the bf16 path: the FORWARD product runs on bf16 MFMA (image and weight rounded to bf16),
+    the weight gradient is the fp32 kernel on the unrounded fp32 image (csrc/conv0.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride):
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return F.conv2d(rb(x), rb(w), b, stride=stride)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gw = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride=ctx.stride)
+        return None, gw, gy.sum(dim=(0, 2, 3)), None
+
+
 def _rfb(x: Tensor, fwd: bool, bwd: bool, on: bool) -> Tensor:
     return _RoundFB.apply(x, fwd, bwd) if on else x
 
@@ -93,7 +110,11 @@ def image_encoder(sd: Dict[str, Tensor], v: Tensor, stride: int = 1,
     """ImageNet2.forward (model.py:79-84): the conv blocks, then image.drop on the last pooled map."""
     n = sum(1 for k in sd if k.startswith("image.conv") and k.endswith(".weight"))
     for i in range(n):
-        v = conv_relu_pool(v, _w16(sd[f"image.conv{i}.weight"], bf16 and i > 0), sd[f"image.conv{i}.bias"], stride)
+        w, b = sd[f"image.conv{i}.weight"], sd[f"image.conv{i}.bias"]
+        if bf16 and i == 0:
+            v = F.max_pool2d(torch.relu(_FirstConvBf16.apply(v, w, b, stride)), 2, 2)
+        else:
+            v = conv_relu_pool(v, _w16(w, bf16), b, stride)
         # bf16 path: pooled maps between blocks are stored as bf16 (the last one stays fp32); the gradient that
         # enters block i's backward is bf16 for i >= 1 (the first block's weight-gradient kernel is fp32)
         v = _rfb(v, fwd=i < n - 1, bwd=i > 0, on=bf16)

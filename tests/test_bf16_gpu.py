@@ -185,6 +185,22 @@ def test_bf16_module_matches_bf16_oracle(do_option, train):
     print(f"[parity-bf16] worst gradient error {worst:.3e}")
 
 
+def test_conv0_bf16_mfma_forward():
+    """First block on bf16 MFMA (image and weights rounded to bf16, fp32 accumulate) against float64 on rounded inputs,
+    incl. a 448-wide image (> 64 KB of LDS)."""
+    ops = _ops()
+    for (B, H, W, Co) in ((2, 30, 32, 64), (1, 22, 448, 64), (3, 17, 20, 32)):
+        g = torch.Generator().manual_seed(H + W)
+        x = torch.randn(B, 3, H, W, generator=g)
+        w = torch.randn(Co, 3, 3, 3, generator=g) * 0.2
+        b = torch.randn(Co, generator=g) * 0.1
+        ref = F.max_pool2d(torch.relu(F.conv2d(rb(x).double(), rb(w).double(), b.double())), 2, 2)
+        p16, am = ops.conv0_fwd(x.to(DEV), w.to(DEV), b.to(DEV), out_dtype=torch.bfloat16, bf16_mfma=True)
+        torch.cuda.synchronize()
+        check(f"conv0 bf16-MFMA fwd {B,H,W,Co}", p16.float().permute(0, 3, 1, 2), ref, 2 ** -8)
+        assert bool(((p16 == 0) == (am == 4)).all())
+
+
 def test_bf16_path_rejects_unsupported_configs():
     from dl_vqa_amd import VqaNet
     cfg = bf16_cfg()

@@ -300,6 +300,120 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
     bias_slab[(int64_t)blockIdx.x * Co + e] = cb[e] + cb[Co + e] + cb[2 * Co + e] + cb[3 * Co + e];
 }
 
+// ------------------------------------------------------------------ wgrad on bf16 MFMA (bf16 path, configs[3])
+// dW[tap][co] = sum over conv-output pixels of x(pixel, tap) * dY(pixel, co): the reduction index (pixels) is the MFMA k.
+//   A (rows = the 27 taps, k = 8 consecutive pixels of a conv row): the image rows are staged as bf16 in THREE copies
+//     shifted by kx = 0, 1, 2, so that a lane's 8 pixels of tap (c, ky, kx) are one aligned ds_read_b128;
+//   B (k = the same 8 pixels, cols = co): rebuilt per lane from the 4 pool windows the pixels fall into (bf16 pooled
+//     gradient + arg-max byte, staged per pooled row): pixel (hs, 2m + parity) of window m keeps the gradient iff
+//     arg-max == 2 hs + parity; the 4 windows serve both conv rows hs = 0, 1 of the pooled row.
+// Persistent workgroups walk pooled rows; each wave keeps 32 x Co partial sums in accumulators for its whole life and
+// the four waves combine through LDS at the end: ONE slab per workgroup (deterministic, no atomics).
+template <int CI, int TN>
+__global__ __launch_bounds__(256) void conv0_wgrad_bf16_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dp,
+                                                               const uint8_t* __restrict__ am, float* slab,
+                                                               float* bias_slab, int B, int H, int W, int Hp, int Wp,
+                                                               int RSTR, int NG) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int K = 9 * CI, Co = 32 * TN;
+  static_assert(K <= 32, "the taps are the 32 rows of one MFMA A operand");
+  const int WpP = 8 * NG;                                   // windows incl. padding (16 pixels = 8 windows per group)
+  char* const P16 = reinterpret_cast<char*>(lds);           // [3 kx][CI][4 rows][RSTR bytes]
+  uint16_t* const dps = reinterpret_cast<uint16_t*>(P16 + 3 * CI * 4 * RSTR);      // [WpP][Co] bf16
+  uint8_t* const ams = reinterpret_cast<uint8_t*>(dps + WpP * Co);                  // [WpP][Co]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int tap = l31 < K ? l31 : 0;                        // rows >= K: any finite data, never written out
+  const int c = tap / 9, t9 = tap - 9 * c, ky = t9 / 3, kx = t9 - 3 * ky;
+  const char* const arow = P16 + ((kx * CI + c) * 4 + ky) * RSTR + 16 * h;   // + hs * RSTR + 32 * g
+  f32x16 acc[TN];
+  float bsum[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bsum[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+  const int rows_total = B * Hp;
+  const int rowv = Wp * Co;
+  for (int row = blockIdx.x; row < rows_total; row += gridDim.x) {
+    const int b = row / Hp, py = row - b * Hp;
+    __syncthreads();   // previous row fully consumed
+    // image rows 2py .. 2py+3 of every channel -> three shifted bf16 copies
+    for (int e = tid; e < CI * 4 * 2 * NG; e += 256) {
+      const int i = e % (2 * NG);                       // chunk of 8 positions
+      const int r = (e / (2 * NG)) & 3;
+      const int cc = e / (2 * NG) / 4;
+      const float* src = x + ((int64_t)(b * CI + cc) * H + 2 * py + r) * W + 8 * i;
+      float v[12];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 f = 8 * i + 4 * q < W ? *reinterpret_cast<const float4*>(src + 4 * q) : f4zero();   // W % 4 == 0
+        v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const uint4 pk = make_uint4(pack_bf16x2(v[s], v[s + 1]), pack_bf16x2(v[s + 2], v[s + 3]),
+                                    pack_bf16x2(v[s + 4], v[s + 5]), pack_bf16x2(v[s + 6], v[s + 7]));
+        *reinterpret_cast<uint4*>(P16 + ((s * CI + cc) * 4 + r) * RSTR + 16 * i) = pk;
+      }
+    }
+    // pooled gradient row and arg-max row (padding windows: gradient 0, arg-max 4)
+    const uint16_t* dprow = dp + (int64_t)row * rowv;
+    const uint8_t* amrow = am + (int64_t)row * rowv;
+    for (int e = tid; e < WpP * Co / 8; e += 256) {
+      const bool in = 8 * e < rowv;                      // Co % 8 == 0: a chunk never straddles the row end
+      reinterpret_cast<uint4*>(dps)[e] = in ? reinterpret_cast<const uint4*>(dprow)[e] : make_uint4(0u, 0u, 0u, 0u);
+      reinterpret_cast<uint2*>(ams)[e] = in ? reinterpret_cast<const uint2*>(amrow)[e] : make_uint2(0x04040404u, 0x04040404u);
+    }
+    __syncthreads();
+    for (int g = wave; g < NG; g += 4) {
+      uint32_t d[TN][4], a8[TN][4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int o = (8 * g + 4 * h + m) * Co + 32 * j + l31;
+          d[j][m] = dps[o];
+          a8[j][m] = ams[o];
+          bsum[j] += a8[j][m] != 4u ? __uint_as_float(d[j][m] << 16) : 0.f;
+        }
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + hs * RSTR + 32 * g));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          uint32_t w[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            w[m] = a8[j][m] == (uint32_t)(2 * hs) ? d[j][m] : (a8[j][m] == (uint32_t)(2 * hs + 1) ? d[j][m] << 16 : 0u);
+          const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // combine the 4 waves of the workgroup through LDS, then ONE partial per workgroup
+  __syncthreads();
+  float* comb = lds;                               // [4][32][Co] floats
+  float* cb = lds + 4 * 32 * Co;                   // [4][Co]
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+      comb[(wave * 32 + k) * Co + 32 * j + l31] = acc[j][r];
+    }
+    const float sv = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+    if (h == 0) cb[wave * Co + 32 * j + l31] = sv;
+  }
+  __syncthreads();
+  float* out = slab + (int64_t)blockIdx.x * 32 * Co;
+  for (int e = tid; e < 32 * Co; e += 256)
+    out[e] = comb[e] + comb[32 * Co + e] + comb[2 * 32 * Co + e] + comb[3 * 32 * Co + e];
+  for (int e = tid; e < Co; e += 256)
+    bias_slab[(int64_t)blockIdx.x * Co + e] = cb[e] + cb[Co + e] + cb[2 * Co + e] + cb[3 * Co + e];
+}
+
 // slab[parts][32][Co] -> dw[co][k]; bias_slab[parts][Co] -> dbias[co].  grid = K + 1 blocks of 256 threads.
 __global__ void conv0_wgrad_reduce_kernel(const float* slab, const float* bias_slab, float* dw, float* dbias,
                                           int parts, int K, int Co) {
@@ -416,6 +530,46 @@ int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* ar
                        RS, PLANE);
   });
   int rc = check_hip(hipGetLastError(), "conv0_wgrad launch");
+  if (rc) return rc;
+  hipLaunchKernelGGL(conv0_wgrad_reduce_kernel, dim3(9 * Ci + 1), dim3(256), 0, s, slab, bias_slab, dw, dbias,
+                     blocks, 9 * Ci, Co);
+  return check_hip(hipGetLastError(), "conv0_wgrad_reduce launch");
+}
+
+int vqa_conv0_wgrad_bf16(const float* x_nchw, const void* dpooled_bf16, const uint8_t* argmax, float* dw, float* dbias,
+                         int B, int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes,
+                         vqa_stream_t stream) {
+  VQA_REQUIRE(x_nchw && dpooled_bf16 && argmax && dw && dbias && workspace, "vqa_conv0_wgrad_bf16: null pointer");
+  VQA_REQUIRE(c0_supported(Ci, H, W, Co, 1) && Ci <= 3, "vqa_conv0_wgrad_bf16: unsupported shape Ci=%d H=%d W=%d Co=%d", Ci, H, W, Co);
+  VQA_REQUIRE(((uintptr_t)dpooled_bf16 % 16) == 0 && ((uintptr_t)argmax % 8) == 0, "vqa_conv0_wgrad_bf16: dpooled / argmax alignment");
+  if (workspace_bytes < vqa_conv0_wgrad_workspace_bytes(Co)) {
+    set_error("vqa_conv0_wgrad_bf16: workspace too small");
+    return VQA_ERR_WORKSPACE;
+  }
+  const int Hp = (H - 2) / 2, Wp = (W - 2) / 2;
+  const int NG = (2 * Wp + 15) / 16;
+  const int RSTR = 32 * NG + 16;                       // bytes per staged image row (+16: rows start on different banks)
+  size_t lds = (size_t)3 * Ci * 4 * RSTR + (size_t)8 * NG * Co * 3;
+  if (lds < (size_t)(4 * 32 + 4) * Co * 4) lds = (size_t)(4 * 32 + 4) * Co * 4;   // the end-of-kernel combine area
+  lds = (lds + 15) & ~(size_t)15;
+  VQA_REQUIRE(lds <= 160 * 1024, "vqa_conv0_wgrad_bf16: image too wide for LDS (W=%d)", W);
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 3) per_cu = 3;
+  int blocks = 256 * per_cu;
+  if (blocks > B * Hp) blocks = B * Hp;
+  float* slab = workspace;
+  float* bias_slab = workspace + (int64_t)kC0Blocks * 32 * Co;
+  hipStream_t s = (hipStream_t)stream;
+  C0_DISPATCH(Ci, Co / 32, {
+    if constexpr (kCI <= 3) {
+      auto kern = conv0_wgrad_bf16_kernel<kCI, kTN>;
+      int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad_bf16)");
+      if (rc0) return rc0;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, static_cast<const uint16_t*>(dpooled_bf16), argmax,
+                         slab, bias_slab, B, H, W, Hp, Wp, RSTR, NG);
+    }
+  });
+  int rc = check_hip(hipGetLastError(), "conv0_wgrad_bf16 launch");
   if (rc) return rc;
   hipLaunchKernelGGL(conv0_wgrad_reduce_kernel, dim3(9 * Ci + 1), dim3(256), 0, s, slab, bias_slab, dw, dbias,
                      blocks, 9 * Ci, Co);

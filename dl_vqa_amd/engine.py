@@ -455,14 +455,15 @@ class Engine:
             dP = ops.to_bf16(dP)
         for l in range(self.L - 1, -1, -1):
             if l == 0 and ctx.fast0:
-                ops.conv0_wgrad(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])
+                if self.bf16:
+                    ops.conv0_wgrad_bf16(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])
+                else:
+                    ops.conv0_wgrad(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])
                 continue
             if self.bf16:
                 ops.conv_wgrad_bf16(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
                                     self.stride, tag=l)
-                # the first block's weight gradient is an fp32 kernel: the gradient it consumes is written as fp32
-                dP = ops.conv_dgrad_bf16(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride,
-                                         out_dtype=torch.float32 if l == 1 else torch.bfloat16, tag=l)
+                dP = ops.conv_dgrad_bf16(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride, tag=l)
                 continue
             ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
                            self.stride, tag=l)

@@ -122,6 +122,17 @@ def conv0_wgrad(x_nchw, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor):
          ws.numel() * 4, stream())
 
 
+def conv0_wgrad_bf16(x_nchw, dpooled16, amax, dw: torch.Tensor, dbias: torch.Tensor):
+    """First block's weight / bias gradient on bf16 MFMA from the bf16 pooled gradient."""
+    assert dpooled16.dtype == torch.bfloat16
+    lib = _lib.load()
+    B, Ci, H, W = x_nchw.shape
+    Co = dw.shape[0]
+    ws = workspace(lib.vqa_conv0_wgrad_workspace_bytes(Co), x_nchw.device)
+    call("vqa_conv0_wgrad_bf16", ptr(x_nchw), ptr(dpooled16), ptr(amax), ptr(dw), ptr(dbias), B, Ci, H, W, Co, ptr(ws),
+         ws.numel() * 4, stream())
+
+
 def dropout(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     y = out if out is not None else torch.empty_like(x)
     call("vqa_dropout", ptr(x), ptr(y), x.numel(), p, seed, stream())

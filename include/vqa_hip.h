@@ -125,6 +125,12 @@ int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* ar
                     int B, int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes,
                     vqa_stream_t stream);
 
+/* bf16 path: the first block's weight gradient on bf16 MFMA (image rounded to bf16 where it is staged, bf16 pooled
+ * gradient as written by vqa_conv3x3_dgrad_bf16, fp32 accumulation, fp32 dw / dbias).  Same workspace query. */
+int vqa_conv0_wgrad_bf16(const float* x_nchw, const void* dpooled_bf16, const uint8_t* argmax, float* dw,
+                         float* dbias, int B, int Ci, int H, int W, int Co, float* workspace,
+                         int64_t workspace_bytes, vqa_stream_t stream);
+
 /* ---- dropout (nn.Dropout, 7 sites: models/model.py:84,156,185,186,194,201,204) ---------------
  * y = x * keep(seed, i) / (1-p); keep() is a counter-based hash, so backward calls the same
  * function on the gradient. In-place allowed. */

@@ -80,8 +80,8 @@ class _RoundFB(torch.autograd.Function):
 
 
 class _FirstConvBf16(torch.autograd.Function):
-    """First conv block of the bf16 path: the FORWARD product runs on bf16 MFMA (image and weight rounded to bf16),
-    the weight gradient is the fp32 kernel on the unrounded fp32 image (csrc/conv0.hip)."""
+    """First conv block of the bf16 path: both products run on bf16 MFMA with the image rounded to bf16 where it is
+    consumed (forward: image and weight; weight gradient: image and the bf16-stored output gradient), csrc/conv0.hip."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride):
@@ -92,7 +92,7 @@ class _FirstConvBf16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gw = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride=ctx.stride)
+        gw = torch.nn.grad.conv2d_weight(rb(x), w.shape, gy, stride=ctx.stride)
         return None, gw, gy.sum(dim=(0, 2, 3)), None
 
 
@@ -116,8 +116,8 @@ def image_encoder(sd: Dict[str, Tensor], v: Tensor, stride: int = 1,
         else:
             v = conv_relu_pool(v, _w16(w, bf16), b, stride)
         # bf16 path: pooled maps between blocks are stored as bf16 (the last one stays fp32); the gradient that
-        # enters block i's backward is bf16 for i >= 1 (the first block's weight-gradient kernel is fp32)
-        v = _rfb(v, fwd=i < n - 1, bwd=i > 0, on=bf16)
+        # enters a block's backward is stored as bf16
+        v = _rfb(v, fwd=i < n - 1, bwd=True, on=bf16)
         if stages is not None:
             stages[f"pool{i}"] = v
     return _drop(v, masks, "image")                                  # model.py:84

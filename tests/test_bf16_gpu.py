@@ -201,6 +201,27 @@ def test_conv0_bf16_mfma_forward():
         assert bool(((p16 == 0) == (am == 4)).all())
 
 
+def test_conv0_bf16_mfma_wgrad():
+    """First block's weight / bias gradient on bf16 MFMA (image rounded to bf16, bf16 pooled gradient) against float64
+    autograd on the rounded operands; odd sizes (pixel groups with padding), a 448-wide image, several images."""
+    ops = _ops()
+    for (B, H, W, Co) in ((2, 30, 32, 64), (1, 14, 448, 64), (3, 17, 20, 32), (5, 40, 44, 64)):
+        g = torch.Generator().manual_seed(H * 3 + W)
+        x = torch.randn(B, 3, H, W, generator=g)
+        w = torch.randn(Co, 3, 3, 3, generator=g) * 0.2
+        b = torch.randn(Co, generator=g) * 0.1
+        wr, br = rb(w).double().requires_grad_(True), b.double().requires_grad_(True)
+        yr = F.max_pool2d(torch.relu(F.conv2d(rb(x).double(), wr, br)), 2, 2)
+        dy = rb(torch.randn(yr.shape, generator=g))
+        yr.backward(dy.double())
+        p16, am = ops.conv0_fwd(x.to(DEV), w.to(DEV), b.to(DEV), out_dtype=torch.bfloat16, bf16_mfma=True)
+        dw, db = torch.empty(Co, 3, 3, 3, device=DEV), torch.empty(Co, device=DEV)
+        ops.conv0_wgrad_bf16(x.to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), am, dw, db)
+        torch.cuda.synchronize()
+        check(f"conv0 bf16-MFMA wgrad {B,H,W,Co}", dw, wr.grad, 3e-5)
+        check(f"conv0 bf16-MFMA bias grad {B,H,W,Co}", db, br.grad, 3e-5)
+
+
 def test_bf16_path_rejects_unsupported_configs():
     from dl_vqa_amd import VqaNet
     cfg = bf16_cfg()

@@ -51,9 +51,9 @@ PROTOTYPES = {
     "vqa_lstm_seq_fwd": (i32, [vp, i32, i64p, i32, i32, i32, i64, i32, vp]),
     "vqa_lstm_seq_bwd": (i32, [vp, i32, i64p, i32, i32, i32, i32, vp]),
     "vqa_lstm_graph_stats": (i32, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
-    "vqa_att_score_fwd": (i32, [f32p, f32p, i32, f32p, f32p, i32, i32, i32, i32, f32, u64, f32p, vp]),
+    "vqa_att_score_fwd": (i32, [vp, i32, f32p, i32, f32p, f32p, i32, i32, i32, i32, f32, u64, f32p, vp]),
     "vqa_att_row_splits": (i32, [i32]),
-    "vqa_att_score_bwd": (i32, [f32p, f32p, i32, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, i32, f32p, f32p, vp]),
+    "vqa_att_score_bwd": (i32, [f32p, f32p, i32, vp, i32, f32p, f32p, i32, i32, i32, i32, f32, u64, i32, f32p, f32p, vp]),
     "vqa_att_apply_fwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, i32, i32, i32, vp]),
     "vqa_att_apply_bwd": (i32, [f32p, i64, f32p, f32p, f32p, f32p, f32p, i32, i32, i32, i32, vp]),
     "vqa_softce_fwd_bwd": (i32, [f32p, i64, i64p, i64p, i32, i32, i32, f32, f32p, f32p, f32p, i64, vp]),

@@ -12,6 +12,22 @@ __device__ __forceinline__ uint32_t f2bf16_pair(float lo, float hi) {      // ro
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// 4 consecutive elements of an fp32 or bf16 row, as floats
+template <bool XB>
+__device__ __forceinline__ float4 ld4(const void* row, int c) {
+  if (XB) {
+    const uint2 w = reinterpret_cast<const uint2*>(row)[c];
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                       __uint_as_float(w.y & 0xffff0000u));
+  }
+  return reinterpret_cast<const float4*>(row)[c];
+}
+template <bool XB>
+__device__ __forceinline__ void st4(void* row, int c, float4 v) {
+  if (XB) reinterpret_cast<uint2*>(row)[c] = make_uint2(f2bf16_pair(v.x, v.y), f2bf16_pair(v.z, v.w));
+  else reinterpret_cast<float4*>(row)[c] = v;
+}
+
 static inline int grid_for(int64_t n, int per_block, int cap = 8192) {
   int64_t b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -251,8 +267,9 @@ __global__ void lstm_cell_bwd_kernel(const float* gates, const float* c_in, cons
 // x = relu(v' (+|*) q') is xs [M][mid]; for do_option '|' x = relu(cat[v', tile(q')]) has 2*mid channels:
 // the v' half is xs, the q' half is relu(qcat[b][:]) replicated over positions (but with its own
 // per-position dropout mask, as nn.Dropout acts on the concatenated tensor).  xld = channels of x.
-template <int G>
-__global__ void att_score_fwd_kernel(const float* xs, const float* wx, int wx_ld, const float* bx, float* score,
+// XB: xs holds bf16 (the bf16 path stores x = relu(v' (+|*) q') as bf16)
+template <int G, bool XB>
+__global__ void att_score_fwd_kernel(const void* xs, const float* wx, int wx_ld, const float* bx, float* score,
                                      int64_t M, int P, int mid, float p, float inv_keep, uint64_t seed,
                                      const float* qcat) {
   const int lane = threadIdx.x & 63;
@@ -263,12 +280,12 @@ __global__ void att_score_fwd_kernel(const float* xs, const float* wx, int wx_ld
   for (int64_t m = wave; m < M; m += nwaves) {
     const int64_t b = m / P;
     const int pp = (int)(m - b * P);
-    const float4* row = reinterpret_cast<const float4*>(xs + m * mid);
+    const char* row = static_cast<const char*>(xs) + m * mid * (XB ? 2 : 4);
     float acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = 0.f;
     for (int c = lane; c < nch; c += 64) {
-      float4 x = row[c];
+      float4 x = ld4<XB>(row, c);
       if (p > 0.f) {
         const uint64_t e = (uint64_t)m * xld + 4 * c;
         x.x *= drop_scale(seed, e, p, inv_keep); x.y *= drop_scale(seed, e + 1, p, inv_keep);
@@ -307,8 +324,8 @@ __global__ void att_score_fwd_kernel(const float* xs, const float* wx, int wx_ld
 // mode 1 '*': xs <- dv' = dz * q'[b]                             dq' part = sum_p dz * v'
 // mode 2 '|': xs <- dv' = dz (v' half);  q' half: dq' part = (q'>0) * sum_p mask_q * sum_g ds*wx[g][mid+n]
 // dwx_part[part][G][xld]: sum_p ds[g] * dropout(x) over the rows of the part (both halves for '|').
-template <int G>
-__global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int wx_ld, float* xs, float* dwx_part,
+template <int G, bool XB>
+__global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int wx_ld, void* xs, float* dwx_part,
                                      float* dq_part, int P, int mid, int RS, float p, float inv_keep, uint64_t seed,
                                      int mode, const float* vprime, const float* qp) {
   const int b = blockIdx.x, rs = blockIdx.y;
@@ -332,8 +349,8 @@ __global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int w
     float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int pp = p0; pp < p1; ++pp) {
       const int64_t m = (int64_t)b * P + pp;
-      float4* xp = reinterpret_cast<float4*>(xs + m * mid) + c;
-      const float4 x = *xp;
+      char* xrow = static_cast<char*>(xs) + m * mid * (XB ? 2 : 4);
+      const float4 x = ld4<XB>(xrow, c);
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
       if (p > 0.f) {
         const uint64_t e = (uint64_t)m * xld + 4 * c;
@@ -373,7 +390,7 @@ __global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int w
         dq.x += qv.x > 0.f ? t2.x * s2.x : 0.f; dq.y += qv.y > 0.f ? t2.y * s2.y : 0.f;
         dq.z += qv.z > 0.f ? t2.z * s2.z : 0.f; dq.w += qv.w > 0.f ? t2.w * s2.w : 0.f;
       }
-      *xp = d;
+      st4<XB>(xrow, c, d);
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -776,15 +793,20 @@ int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out,
     default: set_error("glimpses=%d unsupported (1..4)", G); return VQA_ERR_INVALID; \
   }
 
-int vqa_att_score_fwd(const float* xs, const float* wx, int wx_ld, const float* bx, float* score, int B, int P, int mid,
-                      int G, float p, uint64_t seed, const float* qcat, vqa_stream_t stream) {
+int vqa_att_score_fwd(const void* xs, int xs_is_bf16, const float* wx, int wx_ld, const float* bx, float* score, int B,
+                      int P, int mid, int G, float p, uint64_t seed, const float* qcat, vqa_stream_t stream) {
   set_launch_tag(-1);
   ProfScope prof(VQA_K_ATT_SCORE_FWD, (hipStream_t)stream);
   VQA_REQUIRE(xs && wx && bx && score && mid % 4 == 0 && wx_ld % 4 == 0 && wx_ld >= (qcat ? 2 * mid : mid),
               "vqa_att_score_fwd: bad args");
   const int64_t M = (int64_t)B * P;
-  DISPATCH_G(G, hipLaunchKernelGGL(att_score_fwd_kernel<kG>, dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx, wx_ld,
-                                   bx, score, M, P, mid, p, KEEP(p), seed, qcat));
+  if (xs_is_bf16) {
+    DISPATCH_G(G, hipLaunchKernelGGL((att_score_fwd_kernel<kG, true>), dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx,
+                                     wx_ld, bx, score, M, P, mid, p, KEEP(p), seed, qcat));
+  } else {
+    DISPATCH_G(G, hipLaunchKernelGGL((att_score_fwd_kernel<kG, false>), dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx,
+                                     wx_ld, bx, score, M, P, mid, p, KEEP(p), seed, qcat));
+  }
   return check_hip(hipGetLastError(), "att_score_fwd launch");
 }
 
@@ -793,7 +815,7 @@ int vqa_att_row_splits(int P) {
   return rs < 1 ? 1 : (rs > 8 ? 8 : rs);
 }
 
-int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, float* xs_inout, float* dwx_part,
+int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, void* xs_inout, int xs_is_bf16, float* dwx_part,
                       float* dq_part, int B, int P, int mid, int G, float p, uint64_t seed, int mode,
                       const float* vprime, const float* qp, vqa_stream_t stream) {
   set_launch_tag(-1);
@@ -804,8 +826,13 @@ int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, float* xs
                   wx_ld >= (mode == 2 ? 2 * mid : mid),
               "vqa_att_score_bwd: mode %d needs its operands (vprime/qp) and a matching wx_ld", mode);
   const int RS = vqa_att_row_splits(P);
-  DISPATCH_G(G, hipLaunchKernelGGL(att_score_bwd_kernel<kG>, dim3(B, RS), dim3(256), 0, STREAM, dscore, wx, wx_ld,
-                                   xs_inout, dwx_part, dq_part, P, mid, RS, p, KEEP(p), seed, mode, vprime, qp));
+  if (xs_is_bf16) {
+    DISPATCH_G(G, hipLaunchKernelGGL((att_score_bwd_kernel<kG, true>), dim3(B, RS), dim3(256), 0, STREAM, dscore, wx, wx_ld,
+                                     xs_inout, dwx_part, dq_part, P, mid, RS, p, KEEP(p), seed, mode, vprime, qp));
+  } else {
+    DISPATCH_G(G, hipLaunchKernelGGL((att_score_bwd_kernel<kG, false>), dim3(B, RS), dim3(256), 0, STREAM, dscore, wx, wx_ld,
+                                     xs_inout, dwx_part, dq_part, P, mid, RS, p, KEEP(p), seed, mode, vprime, qp));
+  }
   return check_hip(hipGetLastError(), "att_score_bwd launch");
 }
 

@@ -256,7 +256,9 @@ class Engine:
         ops.gemm(q_in, P["attention.q_lin.weight"], qp, B, mid, Q, lda=ld_q, bias1=P["attention.q_lin.bias"], tag=20)
         # x = relu(v' + q') | relu(v' * q') | relu(cat[v', q'])  (model.py:188-193); v' itself is only kept for
         # '*' (its backward needs it), as the aux output of the same GEMM
-        xs = new(B * Pn, mid)
+        # (bf16 path: x is stored as bf16 -- it is streamed three more times and becomes, overwritten in place by
+        # d loss / d v', the bf16 operand of both v_conv gradient products)
+        xs = torch.empty(B * Pn, mid, dtype=torch.bfloat16 if self.bf16 else torch.float32, device=dev)
         mode = self.att_mode
         vprime = new(B * Pn, mid) if (mode == 1 and keep) else None
         if self.bf16:
@@ -344,8 +346,8 @@ class Engine:
         wv = P["attention.v_conv.weight"]
         if self.bf16:
             # both v_conv gradient products on bf16 MFMA: dW = dx'^T . v_in (both operands reduction-major),
-            # dv_in = dx' . Wv (Wv [mid][C] as the [K][N] operand); one conversion pass over dx'
-            dx16 = ops.to_bf16(dxpre)
+            # dv_in = dx' . Wv (Wv [mid][C] as the [K][N] operand); dx' already is bf16 (written in place over x)
+            dx16 = dxpre
             ops.gemm_bf16(dx16, ctx.v16.view(B * Pn, C), Gr["attention.v_conv.weight"].view(mid, C), mid, C, B * Pn,
                           transA=True, transB=False, lda=mid, ldb=C, tag=44)
             if ctx.p_att > 0:       # dvn += dropout-mask * (dx' . Wv): one pass joins the two branches

@@ -240,7 +240,8 @@ def att_score_fwd(xs, wx, bx, B, P, p: float, seed: int, qcat=None) -> torch.Ten
     G, xld = wx.shape[0], wx.shape[1]
     mid = xld // 2 if qcat is not None else xld
     score = torch.empty(B, G, P, dtype=torch.float32, device=xs.device)
-    call("vqa_att_score_fwd", ptr(xs), ptr(wx), xld, ptr(bx), ptr(score), B, P, mid, G, p, seed, ptr(qcat), stream())
+    call("vqa_att_score_fwd", ptr(xs), int(xs.dtype == torch.bfloat16), ptr(wx), xld, ptr(bx), ptr(score), B, P, mid, G, p,
+         seed, ptr(qcat), stream())
     return score
 
 
@@ -251,8 +252,8 @@ def att_score_bwd(dscore, wx, xs_inout, B, P, p: float, seed: int, mode: int = 0
     RS = lib.vqa_att_row_splits(P)
     dwx_part = torch.empty(B * RS, G * xld, dtype=torch.float32, device=wx.device)
     dq_part = torch.empty(B * RS, mid, dtype=torch.float32, device=wx.device)
-    call("vqa_att_score_bwd", ptr(dscore), ptr(wx), xld, ptr(xs_inout), ptr(dwx_part), ptr(dq_part), B, P, mid, G, p,
-         seed, mode, ptr(vprime), ptr(qp), stream())
+    call("vqa_att_score_bwd", ptr(dscore), ptr(wx), xld, ptr(xs_inout), int(xs_inout.dtype == torch.bfloat16), ptr(dwx_part),
+         ptr(dq_part), B, P, mid, G, p, seed, mode, ptr(vprime), ptr(qp), stream())
     return dwx_part, dq_part, RS
 
 

@@ -207,16 +207,16 @@ int vqa_lstm_graph_stats(int* replays, int* builds, int* plain);
  * x = relu(v' (+|*) q') comes from vqa_gemm(rowgroup = q') as xs[m][n]; for do_option '|' (model.py:192)
  * x = relu(cat[v', tile(q')]) has 2*mid channels: xs holds the v' half and qcat = q' [B][mid] the other.
  * score[b][g][p] = bx[g] + sum_n dropout(x[b*P+p][n]) * wx[g*wx_ld + n]            (x_conv, model.py:194) */
-int vqa_att_score_fwd(const float* xs, const float* wx, int wx_ld, const float* bx, float* score, int B,
-                      int P, int mid, int G, float p, uint64_t seed, const float* qcat /* '|' only */,
-                      vqa_stream_t stream);
+int vqa_att_score_fwd(const void* xs, int xs_is_bf16 /* the bf16 path stores x as bf16 */, const float* wx, int wx_ld,
+                      const float* bx, float* score, int B, int P, int mid, int G, float p, uint64_t seed,
+                      const float* qcat /* '|' only */, vqa_stream_t stream);
 /* Backward of the score + combine stage, in place on xs.  mode: 0 '+', 1 '*', 2 '|'.
  *   xs      <- gradient w.r.t. v' (what the v_conv dW / dX GEMMs consume)
  *   dq_part[b*RS+rs][mid]      partial sums of the gradient w.r.t. q' (RS = vqa_att_row_splits(P))
  *   dwx_part[b*RS+rs][G][xld]  partial sums of the x_conv weight gradient, xld = mid (2*mid for '|')
  * '*' needs vprime = the raw v' (aux output of the forward GEMM) and qp = q'; '|' needs qp. */
 int vqa_att_row_splits(int P);
-int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, float* xs_inout, float* dwx_part,
+int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, void* xs_inout, int xs_is_bf16, float* dwx_part,
                       float* dq_part, int B, int P, int mid, int G, float p, uint64_t seed, int mode,
                       const float* vprime, const float* qp, vqa_stream_t stream);
 /* probs = softmax_p(score); out[b*out_ld + g*C + c] = sum_p probs[b][g][p] * vn[b][p][c] */

@@ -192,12 +192,13 @@ def attention_scores(sd: Dict[str, Tensor], v: Tensor, q: Tensor, do_option: str
     vv = _rfb(torch.einsum("bchw,mc->bmhw", v_in, wv[:, :, 0, 0]), fwd=False, bwd=True, on=bf16)
     qq = _drop(q, masks, "att_q") @ sd["attention.q_lin.weight"].t() + sd["attention.q_lin.bias"]  # model.py:186
     qq = qq[:, :, None, None].expand_as(vv)     # tile_question_over_image (model.py:224-231)
+    # bf16 path: x = relu(v' (+|*) q') is stored as bf16 (the v' half only for '|': the q' half is never materialised)
     if do_option == "*":
-        x = torch.relu(vv * qq)
+        x = _rfb(torch.relu(vv * qq), fwd=True, bwd=False, on=bf16)
     elif do_option == "+":
-        x = torch.relu(vv + qq)
+        x = _rfb(torch.relu(vv + qq), fwd=True, bwd=False, on=bf16)
     elif do_option == "|":
-        x = torch.relu(torch.cat([vv, qq], dim=1))
+        x = torch.cat([_rfb(torch.relu(vv), fwd=True, bwd=False, on=bf16), torch.relu(qq)], dim=1)
     else:
         raise ValueError(do_option)
     wx = sd["attention.x_conv.weight"][:, :, 0, 0]

@@ -9,6 +9,15 @@ namespace vqa {
 
 using Cfg128 = TileCfg<128, 128, 2, 2>;
 using Cfg128x64 = TileCfg<128, 64, 2, 2>;
+// 256-row tiles (8 MFMA waves + 4 loader waves, one workgroup per CU): a third fewer staged bytes per MFMA than two
+// 128x128 workgroups -- on bf16 MFMA the kernels are bound by exactly those bytes (VQA_BIG_TILES=1 selects them)
+using Cfg256x128 = TileCfg<256, 128, 4, 2, 4, 2>;
+using Cfg256x64 = TileCfg<256, 64, 4, 2, 4, 2>;
+#ifndef VQA_BF16_FWD_PF
+#define VQA_BF16_FWD_PF 2
+#endif
+using Cfg128x64L8 = TileCfg<128, 64, 2, 2, 8, 2>;   // 8 loader waves: the bf16 routing (2.5 VALU per element) is the long pole of dgrad
+using Cfg128F = TileCfg<128, 128, 2, 2, 4, VQA_BF16_FWD_PF>;     // forward: plain copies, a third ring slot fits the registers
 
 // ------------------------------------------------------------------ bf16 path launchers (conv_bf16.inc)
 using CfgWb = TileCfg<128, 128, 2, 2, 4, 2>;      // bf16 wgrad: both operands through the transpose-read image
@@ -109,8 +118,11 @@ int vqa_conv3x3_relu_pool_fwd_bf16(const void* x, const void* wfT, const float* 
     const char* xc = static_cast<const char*>(x) + (int64_t)b0 * H * W * CiP * 2;
     const int64_t po = (int64_t)b0 * g1.Hp * g1.Wp * Co;
     void* pc = static_cast<char*>(pooled) + po * (pooled_is_bf16 ? 2 : 4);
-    if (Co > 64) rc = pooled_is_bf16 ? launch_fwd_bf16<Cfg128, true>(xc, wfT, bias, pc, argmax + po, g, s)
-                                     : launch_fwd_bf16<Cfg128, false>(xc, wfT, bias, pc, argmax + po, g, s);
+    if (Co > 64 && knobs().big_tiles == 1)
+      rc = pooled_is_bf16 ? launch_fwd_bf16<Cfg256x128, true>(xc, wfT, bias, pc, argmax + po, g, s)
+                          : launch_fwd_bf16<Cfg256x128, false>(xc, wfT, bias, pc, argmax + po, g, s);
+    else if (Co > 64) rc = pooled_is_bf16 ? launch_fwd_bf16<Cfg128F, true>(xc, wfT, bias, pc, argmax + po, g, s)
+                                     : launch_fwd_bf16<Cfg128F, false>(xc, wfT, bias, pc, argmax + po, g, s);
     else rc = pooled_is_bf16 ? launch_fwd_bf16<Cfg128x64, true>(xc, wfT, bias, pc, argmax + po, g, s)
                              : launch_fwd_bf16<Cfg128x64, false>(xc, wfT, bias, pc, argmax + po, g, s);
     if (rc) return rc;
@@ -135,10 +147,18 @@ int vqa_conv3x3_dgrad_bf16(const void* dpooled, const uint8_t* argmax, const voi
     const int64_t po = (int64_t)b0 * g1.Hp * g1.Wp * Co, xo = (int64_t)b0 * H * W * CiP;
     const char* dpc = static_cast<const char*>(dpooled) + po * 2;
     void* dxc = static_cast<char*>(dx) + xo * (dx_is_bf16 ? 2 : 4);
-    if (CiP > 64) rc = dx_is_bf16 ? launch_dgrad_bf16<Cfg128, true>(dpc, argmax + po, wdT, dxc, g, s)
+    if (knobs().big_tiles == 1)
+      rc = CiP > 64 ? (dx_is_bf16 ? launch_dgrad_bf16<Cfg256x128, true>(dpc, argmax + po, wdT, dxc, g, s)
+                                  : launch_dgrad_bf16<Cfg256x128, false>(dpc, argmax + po, wdT, dxc, g, s))
+                    : (dx_is_bf16 ? launch_dgrad_bf16<Cfg256x64, true>(dpc, argmax + po, wdT, dxc, g, s)
+                                  : launch_dgrad_bf16<Cfg256x64, false>(dpc, argmax + po, wdT, dxc, g, s));
+    else if (CiP > 64) rc = dx_is_bf16 ? launch_dgrad_bf16<Cfg128, true>(dpc, argmax + po, wdT, dxc, g, s)
                                   : launch_dgrad_bf16<Cfg128, false>(dpc, argmax + po, wdT, dxc, g, s);
-    else rc = dx_is_bf16 ? launch_dgrad_bf16<Cfg128x64, true>(dpc, argmax + po, wdT, dxc, g, s)
-                         : launch_dgrad_bf16<Cfg128x64, false>(dpc, argmax + po, wdT, dxc, g, s);
+    else if (knobs().big_tiles == 0)
+      rc = dx_is_bf16 ? launch_dgrad_bf16<Cfg128x64, true>(dpc, argmax + po, wdT, dxc, g, s)
+                      : launch_dgrad_bf16<Cfg128x64, false>(dpc, argmax + po, wdT, dxc, g, s);
+    else rc = dx_is_bf16 ? launch_dgrad_bf16<Cfg128x64L8, true>(dpc, argmax + po, wdT, dxc, g, s)
+                         : launch_dgrad_bf16<Cfg128x64L8, false>(dpc, argmax + po, wdT, dxc, g, s);
     if (rc) return rc;
   }
   return VQA_OK;

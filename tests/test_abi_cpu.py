@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu():
     assert rc == 1 and b"null operand" in lib.vqa_last_error()
     rc = lib.vqa_conv3x3_relu_pool_fwd(16, 16, 16, 16, 16, 1, 8, 8, 6, 8, 1, 0, None)   # CiP = 6
     assert rc == 1 and b"multiples of 4" in lib.vqa_last_error()
-    rc = lib.vqa_att_score_fwd(16, 16, 8, 16, 16, 1, 4, 8, 9, 0.0, 0, None, None)        # G = 9
+    rc = lib.vqa_att_score_fwd(16, 0, 16, 8, 16, 16, 1, 4, 8, 9, 0.0, 0, None, None)     # G = 9
     assert rc == 1 and b"glimpses" in lib.vqa_last_error()
     assert lib.vqa_gemm_workspace_bytes(256, 1024, 2560) > 0       # split-K plan for a skinny GEMM
     assert lib.vqa_gemm_workspace_bytes(4096, 4096, 64) == 0

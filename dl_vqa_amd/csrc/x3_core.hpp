@@ -1,0 +1,204 @@
+// fp32 contraction on the bf16 matrix cores: the "3 x bf16" instantiation of the GEMM engine for gfx950.
+//
+// Every fp32 operand element is split EXACTLY into three bf16 terms  x = hi + mid + lo  (hi = RNE(x), mid = RNE(x - hi),
+// lo = x - hi - mid: 8 + 8 + 8 significand bits cover fp32's 24), and a product a*b is accumulated in fp32 from the six
+// partial products whose weight is at least 2^-16 of it:
+//     a*b ~= a_hi*b_hi + a_hi*b_mid + a_mid*b_hi + a_mid*b_mid + a_hi*b_lo + a_lo*b_hi
+// The three dropped terms (mid*lo, lo*mid, lo*lo) are below 2^-24 |a*b| each -- smaller than the rounding of ONE fp32
+// product -- so the result carries fp32 accuracy (tests/test_x3_gpu.py measures it against float64 beside the native fp32
+// MFMA path), while six v_mfma_f32_32x32x16_bf16 (32 cycles each) replace the eight v_mfma_f32_32x32x2_f32 (64 cycles
+// each) of a 32x32x16 block: 2.67x the fp32 MFMA rate (2 500 / 6 = 416.7 TFLOP/s fp32-equivalent on MI355X).
+//
+// Structure: the fp32 engine's loaders unchanged (same Raw rings, same 32-element K-step, fp32 arg-max routing), the
+// split done by the loader waves when a K-step goes to LDS, three bf16 planes per operand in LDS, the bf16 engine's
+// fragment reads (ds_read_b128 for k-contiguous operands, ds_read_b64_tr_b16 for reduction-major ones).  A K-step stage
+// of a (BM + BN)-row tile takes 240 bytes per row, so the tiles run one workgroup per CU (192 x 128: 153.6 KB) with
+// fully double-buffered fragments (256 VGPRs per wave).
+#pragma once
+#include "bf16_core.hpp"
+
+namespace vqa {
+
+constexpr int XRS = 20;          // dwords per row per plane of a type R image: 32 bf16 + 4 dwords of padding
+constexpr int XROW = 3 * XRS;    // dwords per row, three planes side by side (60 rows x ... : 16 rows cover the 64 banks once)
+
+template <int TILE>
+struct LdsImageX {               // type C image: per plane [k 0..31][tile] of bf16, row stride = 64 / 192 (mod 256) bytes
+  static constexpr int RAW = TILE * 2;
+  static constexpr int RSB = RAW + ((RAW % 256 == 64 || RAW % 256 == 192) ? 0 : 64);
+  static constexpr int PLANE = BK * RSB;            // bytes
+  static constexpr int DWORDS = 3 * PLANE / 4;
+};
+template <class Cfg, bool AR, bool BR>
+struct SmemLayoutX {
+  static constexpr int ABUF = AR ? XROW * Cfg::BM : LdsImageX<Cfg::BM>::DWORDS;   // dwords per stage
+  static constexpr int BBUF = BR ? XROW * Cfg::BN : LdsImageX<Cfg::BN>::DWORDS;
+  static constexpr int BYTES = 2 * (ABUF + BBUF) * 4;
+  static_assert(BYTES <= 160 * 1024, "tile does not fit the LDS");
+};
+
+// v = hi + mid + lo, four elements at a time; each output is two dwords of packed bf16 (element 0 in the low half).
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+  hi.x = pack_bf16x2(v.x, v.y);
+  hi.y = pack_bf16x2(v.z, v.w);
+  const float r0 = v.x - bf16_lo(hi.x), r1 = v.y - bf16_hi(hi.x), r2 = v.z - bf16_lo(hi.y), r3 = v.w - bf16_hi(hi.y);
+  mid.x = pack_bf16x2(r0, r1);
+  mid.y = pack_bf16x2(r2, r3);
+  lo.x = pack_bf16x2(r0 - bf16_lo(mid.x), r1 - bf16_hi(mid.x));
+  lo.y = pack_bf16x2(r2 - bf16_lo(mid.y), r3 - bf16_hi(mid.y));
+}
+
+// ---------------------------------------------------------------- loader role
+template <class Cfg, class L, bool IS_A>
+__device__ __forceinline__ void stage_store_x(const L& ld, const typename L::Raw& raw, float* dst, int ltid) {
+  constexpr int NV = IS_A ? Cfg::NVA : Cfg::NVB;
+  constexpr int TILE = IS_A ? Cfg::BM : Cfg::BN;
+  float4 r[NV];
+  ld.finish(raw, r);
+  char* const d = reinterpret_cast<char*>(dst);
+#pragma unroll
+  for (int p = 0; p < NV; ++p) {
+    uint2 h, m, l;
+    split4(r[p], h, m, l);
+    if constexpr (L::kTypeR) {
+      char* q = d + (StageMap<Cfg::LT>::r_row(ltid, p) * XROW + 2 * StageMap<Cfg::LT>::r_chunk(ltid)) * 4;
+      *reinterpret_cast<uint2*>(q) = h;
+      *reinterpret_cast<uint2*>(q + XRS * 4) = m;
+      *reinterpret_cast<uint2*>(q + 2 * XRS * 4) = l;
+    } else {
+      char* q = d + StageMap<Cfg::LT>::c_krow(ltid) * LdsImageX<TILE>::RSB + 8 * StageMap<Cfg::LT>::c_chunk(ltid, p);
+      *reinterpret_cast<uint2*>(q) = h;
+      *reinterpret_cast<uint2*>(q + LdsImageX<TILE>::PLANE) = m;
+      *reinterpret_cast<uint2*>(q + 2 * LdsImageX<TILE>::PLANE) = l;
+    }
+  }
+}
+
+template <class Cfg, class AL, class BL>
+__device__ __forceinline__ void loader_loop_x(AL& al, BL& bl, int ks0, int ks1, float* smem) {
+  constexpr int D = Cfg::PREFETCH;
+  using SL = SmemLayoutX<Cfg, AL::kTypeR, BL::kTypeR>;
+  const int ltid = loader_tid<Cfg>();
+  float* const As0 = smem;
+  float* const Bs0 = smem + 2 * SL::ABUF;
+  typename AL::Raw rawA[D];
+  typename BL::Raw rawB[D];
+  al.issue(ks0, rawA[0]);
+  bl.issue(ks0, rawB[0]);
+  stage_store_x<Cfg, AL, true>(al, rawA[0], As0, ltid);
+  stage_store_x<Cfg, BL, false>(bl, rawB[0], Bs0, ltid);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    al.issue(ks0 + 1 + d, rawA[d]);
+    bl.issue(ks0 + 1 + d, rawB[d]);
+  }
+  __syncthreads();
+  for (int ks = ks0; ks < ks1; ks += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (ks + d < ks1) {
+        const int nxt = ((ks + d - ks0) & 1) ^ 1;
+        stage_store_x<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid);
+        al.issue(ks + d + 1 + D, rawA[d]);
+        stage_store_x<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid);
+        bl.issue(ks + d + 1 + D, rawB[d]);
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- MFMA role
+// One K-step = 2 groups m = 0, 1 of 6 * TM * TN MFMAs; the fragments of the next group are fetched before the MFMAs of
+// the current one; the K-step barrier sits in front of the last group (every fragment of the stage is in registers).
+template <class Cfg, bool AR, bool BR>
+__device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1, const float* smem) {
+  using SL = SmemLayoutX<Cfg, AR, BR>;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const int l31 = lane & 31, h = lane >> 5, i16 = lane & 15, grp = (lane >> 4) & 1;
+  constexpr int RSA = LdsImageX<Cfg::BM>::RSB, RSBb = LdsImageX<Cfg::BN>::RSB;
+  constexpr int PLA = AR ? XRS * 4 : LdsImageX<Cfg::BM>::PLANE;     // plane stride, bytes
+  constexpr int PLB = BR ? XRS * 4 : LdsImageX<Cfg::BN>::PLANE;
+  const int a_off = AR ? ((wm * Cfg::WM + l31) * XROW + 4 * h) * 4
+                       : (8 * h + (i16 >> 2)) * RSA + (wm * Cfg::WM + 16 * grp + 4 * (i16 & 3)) * 2;
+  const int b_off = BR ? ((wn * Cfg::WN + l31) * XROW + 4 * h) * 4
+                       : (8 * h + (i16 >> 2)) * RSBb + (wn * Cfg::WN + 16 * grp + 4 * (i16 & 3)) * 2;
+  const char* const sm = reinterpret_cast<const char*>(smem);
+  const char* const As0 = sm + a_off;
+  const char* const Bs0 = sm + 2 * SL::ABUF * 4 + b_off;
+  bf16x8 a[2][3][Cfg::TM], b[2][3][Cfg::TN];
+  auto trread = [](const char* p) -> s16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p)); };
+  auto fetch = [&](const char* ap, const char* bp, int m, int buf) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        if (AR) {
+          a[buf][pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(ap + pl * PLA + 32 * i * XROW * 4 + 32 * m));
+        } else {
+          const char* q = ap + pl * PLA + (16 * m) * RSA + 64 * i;
+          const s16x4 lo = trread(q), hi = trread(q + 4 * RSA);
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          a[buf][pl][i] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        if (BR) {
+          b[buf][pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(bp + pl * PLB + 32 * j * XROW * 4 + 32 * m));
+        } else {
+          const char* q = bp + pl * PLB + (16 * m) * RSBb + 64 * j;
+          const s16x4 lo = trread(q), hi = trread(q + 4 * RSBb);
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          b[buf][pl][j] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+    }
+  };
+  // plane pairs, small terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); consecutive MFMAs go to
+  // different accumulators
+  auto mma = [&](int buf) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[buf][PA[t]][i], b[buf][PB[t]][j], acc[i][j], 0, 0, 0);
+  };
+  __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
+  __syncthreads();
+  fetch(As0, Bs0, 0, 0);
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int cur = (ks - ks0) & 1;
+    fetch(As0 + cur * SL::ABUF * 4, Bs0 + cur * SL::BBUF * 4, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();   // every fragment of this stage is in registers; the next stage is complete
+    if (ks + 1 < ks1) fetch(As0 + (cur ^ 1) * SL::ABUF * 4, Bs0 + (cur ^ 1) * SL::BBUF * 4, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Whole contraction over K-steps [ks0, ks1): true for MFMA waves (they hold the accumulators), false for loader waves.
+template <class Cfg, class AL, class BL, class Init>
+__device__ __forceinline__ bool gemm_mainloop_x(Init&& init, f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1,
+                                                float* smem) {
+  if (is_loader_wave<Cfg>()) {
+    AL al; BL bl;
+    init(al, bl);
+    loader_loop_x<Cfg>(al, bl, ks0, ks1, smem);
+    return false;
+  }
+  mfma_loop_x<Cfg, AL::kTypeR, BL::kTypeR>(acc, ks0, ks1, smem);
+  return true;
+}
+
+}  // namespace vqa

@@ -66,33 +66,39 @@ def conv_out_hw(H: int, W: int, stride: int) -> Tuple[int, int]:
     return ((H - 3) // stride + 1) // 2, ((W - 3) // stride + 1) // 2
 
 
-def conv_fwd(x: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor, stride: int = 1, tag: int = 0):
-    """x NHWC [B,H,W,CiP] -> (pooled [B,Hp,Wp,Co], argmax uint8 same shape)."""
+def conv_x3_supported(H: int, W: int, CiP: int, Co: int, stride: int) -> bool:
+    return bool(_lib.load().vqa_conv3x3_x3_supported(H, W, CiP, Co, stride))
+
+
+def conv_fwd(x: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False):
+    """x NHWC [B,H,W,CiP] -> (pooled [B,Hp,Wp,Co], argmax uint8 same shape).  x3: fp32 on the bf16 matrix cores
+    (exact 3 x bf16 operand split, csrc/x3_core.hpp) instead of the fp32 MFMA."""
     B, H, W, CiP = x.shape
     Co = wf.shape[1]
     Hp, Wp = conv_out_hw(H, W, stride)
     pooled = torch.empty(B, Hp, Wp, Co, dtype=torch.float32, device=x.device)
     amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x.device)
-    call("vqa_conv3x3_relu_pool_fwd", ptr(x), ptr(wf), ptr(bias), ptr(pooled), ptr(amax), B, H, W, CiP, Co,
-         stride, tag, stream())
+    call("vqa_conv3x3_relu_pool_fwd_x3" if x3 else "vqa_conv3x3_relu_pool_fwd", ptr(x), ptr(wf), ptr(bias), ptr(pooled),
+         ptr(amax), B, H, W, CiP, Co, stride, tag, stream())
     return pooled, amax
 
 
-def conv_dgrad(dpooled, amax, wd, x_shape, stride: int = 1, tag: int = 0, out=None) -> torch.Tensor:
+def conv_dgrad(dpooled, amax, wd, x_shape, stride: int = 1, tag: int = 0, out=None, x3: bool = False) -> torch.Tensor:
     B, H, W, CiP = x_shape
     Co = dpooled.shape[3]
     dx = out if out is not None else torch.empty(B, H, W, CiP, dtype=torch.float32, device=dpooled.device)
-    call("vqa_conv3x3_dgrad", ptr(dpooled), ptr(amax), ptr(wd), ptr(dx), B, H, W, CiP, Co, stride, tag, stream())
+    call("vqa_conv3x3_dgrad_x3" if x3 else "vqa_conv3x3_dgrad", ptr(dpooled), ptr(amax), ptr(wd), ptr(dx), B, H, W, CiP,
+         Co, stride, tag, stream())
     return dx
 
 
-def conv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: int = 1, tag: int = 0):
+def conv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False):
     lib = _lib.load()
     B, H, W, CiP = x.shape
     Co, Ci = dw.shape[0], dw.shape[1]
-    nbytes = lib.vqa_conv3x3_wgrad_workspace_bytes(B, H, W, CiP, Co, stride)
+    nbytes = (lib.vqa_conv3x3_wgrad_x3_workspace_bytes if x3 else lib.vqa_conv3x3_wgrad_workspace_bytes)(B, H, W, CiP, Co, stride)
     ws = workspace(nbytes, x.device)
-    call("vqa_conv3x3_wgrad", ptr(x), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co, stride,
+    call("vqa_conv3x3_wgrad_x3" if x3 else "vqa_conv3x3_wgrad", ptr(x), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co, stride,
          ptr(ws), ws.numel() * 4, tag, stream())
 
 

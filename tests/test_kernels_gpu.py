@@ -462,6 +462,25 @@ def test_lstm_sequence_matches_unfused_path():
     check("seq vs unfused dc", b["dc"], dc.double(), 2e-5)
 
 
+@pytest.mark.parametrize("B,P,C,G", [(2, 676, 256, 2), (2, 70, 130, 3), (3, 100, 72, 1), (2, 17, 64, 4), (1, 65, 8, 2)])
+def test_attention_apply_fwd_shapes(B, P, C, G):
+    """softmax over positions + weighted sum, both the 16-byte-load form (C % 4 == 0) and the scalar one, channel
+    blocks that are not full, position counts around the 64-position unroll, an output row stride wider than G*C."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + P + C)
+    score = torch.randn(B, G, P, generator=g) * 2
+    vn = torch.randn(B, P, C, generator=g)
+    pr = torch.softmax(score.double(), dim=-1)
+    ref = torch.einsum("bgp,bpc->bgc", pr, vn.double()).reshape(B, G * C)
+    ld = G * C + 12
+    out = torch.full((B, ld), 7.0, device=DEV)
+    probs = ops.att_apply_fwd(score.to(DEV), vn.to(DEV), out, ld)
+    torch.cuda.synchronize()
+    check(f"att_apply_fwd probs {B,P,C,G}", probs, pr, 3e-6)
+    check(f"att_apply_fwd out {B,P,C,G}", out[:, :G * C], ref, 3e-6)
+    assert bool((out[:, G * C:] == 7.0).all())
+
+
 def test_attention_score_and_apply():
     ops = _ops()
     g = torch.Generator().manual_seed(8)

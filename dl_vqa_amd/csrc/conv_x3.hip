@@ -140,6 +140,12 @@ static WgradPlanX plan_wgrad_x3(const ConvGeom& g) {
   return p;
 }
 
+// the operand split on its own (tests): planes of n bf16 each
+__global__ void x3_split_kernel(const float4* x, uint2* hi, uint2* mid, uint2* lo, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) split4(x[i], hi[i], mid[i], lo[i], split_consts());
+}
+
 static bool x3_conv_ok(int CiP, int Co, int Wp) { return CiP % BK == 0 && Co % BK == 0 && 2 * Wp >= BK; }
 
 }  // namespace vqa
@@ -147,6 +153,14 @@ static bool x3_conv_ok(int CiP, int Co, int Wp) { return CiP % BK == 0 && Co % B
 using namespace vqa;
 
 extern "C" {
+
+int vqa_x3_split(const float* x, void* hi, void* mid, void* lo, int64_t n, vqa_stream_t stream) {
+  VQA_REQUIRE(x && hi && mid && lo && n > 0 && n % 4 == 0, "vqa_x3_split: bad args (n=%lld must be a multiple of 4)", (long long)n);
+  hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), static_cast<uint2*>(hi), static_cast<uint2*>(mid),
+                     static_cast<uint2*>(lo), n / 4);
+  return check_hip(hipGetLastError(), "x3_split launch");
+}
 
 int vqa_conv3x3_x3_supported(int H, int W, int CiP, int Co, int stride) {
   const ConvGeom g = make_geom(1, H, W, CiP, Co, stride);

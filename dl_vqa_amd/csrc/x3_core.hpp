@@ -19,8 +19,11 @@
 
 namespace vqa {
 
-constexpr int XRS = 20;          // dwords per row per plane of a type R image: 32 bf16 + 4 dwords of padding
-constexpr int XROW = 3 * XRS;    // dwords per row, three planes side by side (60 rows x ... : 16 rows cover the 64 banks once)
+// type R image: per plane [row][XRS dwords] = 32 bf16 + 4 dwords of padding; three planes one after the other.  Row stride
+// 20 dwords: the 16 rows of a ds_read_b128 pass start at 16 distinct multiples of 4 banks (conflict-free), and the four
+// rows of a ds_write_b64 half-wave (8 lanes x 8 bytes per row) overlap in 12 of 64 banks only (three planes side by side
+// in one 60-dword row overlapped in 36 of 64).
+constexpr int XRS = 20;
 
 template <int TILE>
 struct LdsImageX {               // type C image: per plane [k 0..31][tile] of bf16, row stride = 64 / 192 (mod 256) bytes
@@ -31,26 +34,54 @@ struct LdsImageX {               // type C image: per plane [k 0..31][tile] of b
 };
 template <class Cfg, bool AR, bool BR>
 struct SmemLayoutX {
-  static constexpr int ABUF = AR ? XROW * Cfg::BM : LdsImageX<Cfg::BM>::DWORDS;   // dwords per stage
-  static constexpr int BBUF = BR ? XROW * Cfg::BN : LdsImageX<Cfg::BN>::DWORDS;
+  static constexpr int ABUF = AR ? 3 * XRS * Cfg::BM : LdsImageX<Cfg::BM>::DWORDS;   // dwords per stage
+  static constexpr int BBUF = BR ? 3 * XRS * Cfg::BN : LdsImageX<Cfg::BN>::DWORDS;
   static constexpr int BYTES = 2 * (ABUF + BBUF) * 4;
   static_assert(BYTES <= 160 * 1024, "tile does not fit the LDS");
 };
 
 // v = hi + mid + lo, four elements at a time; each output is two dwords of packed bf16 (element 0 in the low half).
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+// hi = RNE(v) (one v_cvt_pk_bf16_f32 per pair); the residual v - hi comes from v_dot2c_f32_bf16 with the constant pairs
+// (-1, 0) / (0, -1): acc = v; acc += hi.lo * -1 + hi.hi * 0 -- exact (the products and the sum are representable), and one
+// instruction per element instead of unpack + subtract.  3.5 VALU instructions per element in all.
+// The constant pairs are handed over in registers the compiler cannot see through: as an inline constant, hipcc (ROCm 7.2)
+// encodes the pair (-1, 0) as the operand "-1.0", which the hardware reads as the 32-bit pattern 0xbf800000 = (0, -1).
+struct SplitConsts { uint32_t lo, hi; };
+__device__ __forceinline__ SplitConsts split_consts() {
+  SplitConsts c;
+  asm volatile("s_mov_b32 %0, 0x0000bf80\n\ts_mov_b32 %1, 0xbf800000" : "=s"(c.lo), "=s"(c.hi));
+  return c;
+}
+__device__ __forceinline__ float resid(uint32_t pk, uint32_t k, float x) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pk), __builtin_bit_cast(bf2, k), x, false);
+}
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo, const SplitConsts k) {
+#ifdef VQA_X3_EXP_NOSPLIT   // timing experiment only (tools/build_x3_variant.sh): no split arithmetic, results are garbage
+  hi = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); mid = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); lo = hi;
+  return;
+#endif
   hi.x = pack_bf16x2(v.x, v.y);
   hi.y = pack_bf16x2(v.z, v.w);
+#ifdef VQA_X3_SPLIT_SUB     // unpack + subtract instead of the dot2 residual (same values)
   const float r0 = v.x - bf16_lo(hi.x), r1 = v.y - bf16_hi(hi.x), r2 = v.z - bf16_lo(hi.y), r3 = v.w - bf16_hi(hi.y);
   mid.x = pack_bf16x2(r0, r1);
   mid.y = pack_bf16x2(r2, r3);
   lo.x = pack_bf16x2(r0 - bf16_lo(mid.x), r1 - bf16_hi(mid.x));
   lo.y = pack_bf16x2(r2 - bf16_lo(mid.y), r3 - bf16_hi(mid.y));
+#else
+  const float r0 = resid(hi.x, k.lo, v.x), r1 = resid(hi.x, k.hi, v.y), r2 = resid(hi.y, k.lo, v.z), r3 = resid(hi.y, k.hi, v.w);
+  mid.x = pack_bf16x2(r0, r1);
+  mid.y = pack_bf16x2(r2, r3);
+  lo.x = pack_bf16x2(resid(mid.x, k.lo, r0), resid(mid.x, k.hi, r1));
+  lo.y = pack_bf16x2(resid(mid.y, k.lo, r2), resid(mid.y, k.hi, r3));
+#endif
 }
 
 // ---------------------------------------------------------------- loader role
 template <class Cfg, class L, bool IS_A>
-__device__ __forceinline__ void stage_store_x(const L& ld, const typename L::Raw& raw, float* dst, int ltid) {
+__device__ __forceinline__ void stage_store_x(const L& ld, const typename L::Raw& raw, float* dst, int ltid,
+                                              const SplitConsts k) {
   constexpr int NV = IS_A ? Cfg::NVA : Cfg::NVB;
   constexpr int TILE = IS_A ? Cfg::BM : Cfg::BN;
   float4 r[NV];
@@ -59,12 +90,12 @@ __device__ __forceinline__ void stage_store_x(const L& ld, const typename L::Raw
 #pragma unroll
   for (int p = 0; p < NV; ++p) {
     uint2 h, m, l;
-    split4(r[p], h, m, l);
+    split4(r[p], h, m, l, k);
     if constexpr (L::kTypeR) {
-      char* q = d + (StageMap<Cfg::LT>::r_row(ltid, p) * XROW + 2 * StageMap<Cfg::LT>::r_chunk(ltid)) * 4;
+      char* q = d + (StageMap<Cfg::LT>::r_row(ltid, p) * XRS + 2 * StageMap<Cfg::LT>::r_chunk(ltid)) * 4;
       *reinterpret_cast<uint2*>(q) = h;
-      *reinterpret_cast<uint2*>(q + XRS * 4) = m;
-      *reinterpret_cast<uint2*>(q + 2 * XRS * 4) = l;
+      *reinterpret_cast<uint2*>(q + TILE * XRS * 4) = m;
+      *reinterpret_cast<uint2*>(q + 2 * TILE * XRS * 4) = l;
     } else {
       char* q = d + StageMap<Cfg::LT>::c_krow(ltid) * LdsImageX<TILE>::RSB + 8 * StageMap<Cfg::LT>::c_chunk(ltid, p);
       *reinterpret_cast<uint2*>(q) = h;
@@ -79,14 +110,15 @@ __device__ __forceinline__ void loader_loop_x(AL& al, BL& bl, int ks0, int ks1, 
   constexpr int D = Cfg::PREFETCH;
   using SL = SmemLayoutX<Cfg, AL::kTypeR, BL::kTypeR>;
   const int ltid = loader_tid<Cfg>();
+  const SplitConsts kc = split_consts();
   float* const As0 = smem;
   float* const Bs0 = smem + 2 * SL::ABUF;
   typename AL::Raw rawA[D];
   typename BL::Raw rawB[D];
   al.issue(ks0, rawA[0]);
   bl.issue(ks0, rawB[0]);
-  stage_store_x<Cfg, AL, true>(al, rawA[0], As0, ltid);
-  stage_store_x<Cfg, BL, false>(bl, rawB[0], Bs0, ltid);
+  stage_store_x<Cfg, AL, true>(al, rawA[0], As0, ltid, kc);
+  stage_store_x<Cfg, BL, false>(bl, rawB[0], Bs0, ltid, kc);
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     al.issue(ks0 + 1 + d, rawA[d]);
@@ -98,9 +130,9 @@ __device__ __forceinline__ void loader_loop_x(AL& al, BL& bl, int ks0, int ks1, 
     for (int d = 0; d < D; ++d) {
       if (ks + d < ks1) {
         const int nxt = ((ks + d - ks0) & 1) ^ 1;
-        stage_store_x<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid);
+        stage_store_x<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid, kc);
         al.issue(ks + d + 1 + D, rawA[d]);
-        stage_store_x<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid);
+        stage_store_x<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid, kc);
         bl.issue(ks + d + 1 + D, rawB[d]);
         __syncthreads();
       }
@@ -119,11 +151,11 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const int l31 = lane & 31, h = lane >> 5, i16 = lane & 15, grp = (lane >> 4) & 1;
   constexpr int RSA = LdsImageX<Cfg::BM>::RSB, RSBb = LdsImageX<Cfg::BN>::RSB;
-  constexpr int PLA = AR ? XRS * 4 : LdsImageX<Cfg::BM>::PLANE;     // plane stride, bytes
-  constexpr int PLB = BR ? XRS * 4 : LdsImageX<Cfg::BN>::PLANE;
-  const int a_off = AR ? ((wm * Cfg::WM + l31) * XROW + 4 * h) * 4
+  constexpr int PLA = AR ? Cfg::BM * XRS * 4 : LdsImageX<Cfg::BM>::PLANE;     // plane stride, bytes
+  constexpr int PLB = BR ? Cfg::BN * XRS * 4 : LdsImageX<Cfg::BN>::PLANE;
+  const int a_off = AR ? ((wm * Cfg::WM + l31) * XRS + 4 * h) * 4
                        : (8 * h + (i16 >> 2)) * RSA + (wm * Cfg::WM + 16 * grp + 4 * (i16 & 3)) * 2;
-  const int b_off = BR ? ((wn * Cfg::WN + l31) * XROW + 4 * h) * 4
+  const int b_off = BR ? ((wn * Cfg::WN + l31) * XRS + 4 * h) * 4
                        : (8 * h + (i16 >> 2)) * RSBb + (wn * Cfg::WN + 16 * grp + 4 * (i16 & 3)) * 2;
   const char* const sm = reinterpret_cast<const char*>(smem);
   const char* const As0 = sm + a_off;
@@ -136,7 +168,7 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
         if (AR) {
-          a[buf][pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(ap + pl * PLA + 32 * i * XROW * 4 + 32 * m));
+          a[buf][pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(ap + pl * PLA + 32 * i * XRS * 4 + 32 * m));
         } else {
           const char* q = ap + pl * PLA + (16 * m) * RSA + 64 * i;
           const s16x4 lo = trread(q), hi = trread(q + 4 * RSA);
@@ -147,7 +179,7 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) {
         if (BR) {
-          b[buf][pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(bp + pl * PLB + 32 * j * XROW * 4 + 32 * m));
+          b[buf][pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(bp + pl * PLB + 32 * j * XRS * 4 + 32 * m));
         } else {
           const char* q = bp + pl * PLB + (16 * m) * RSBb + 64 * j;
           const s16x4 lo = trread(q), hi = trread(q + 4 * RSBb);

@@ -64,13 +64,20 @@ class Engine:
         # bf16 path (BASELINE configs[3]): conv blocks 1.. and the v_conv products on bf16 MFMA (fp32 accumulate),
         # activations between the conv blocks stored as bf16; parameters, LSTM, reductions and the optimiser stay
         # fp32.  Opt-in; fp32 is the parity path.
-        if compute_dtype not in ("fp32", "bf16"):
-            raise ValueError(f"compute_dtype {compute_dtype!r} (fp32 or bf16)")
+        # fp32x3: the same fp32 tensors everywhere, but the conv blocks' contractions run on the bf16 matrix cores with every
+        # fp32 operand split exactly into three bf16 terms (csrc/x3_core.hpp) -- fp32-level accuracy, opt-in.
+        if compute_dtype not in ("fp32", "bf16", "fp32x3"):
+            raise ValueError(f"compute_dtype {compute_dtype!r} (fp32, fp32x3 or bf16)")
         self.bf16 = compute_dtype == "bf16"
+        self.x3 = compute_dtype == "fp32x3"
         if self.bf16:
             if self.L < 2 or any(ch % 64 for ch in self.channels[1:]) or self.mid % 8 or self.stride != 1:
                 raise ValueError("the bf16 path needs >= 2 conv blocks, stride 1 and channel counts that are multiples "
                                  f"of 64 after the first block (num_channels={self.channels}, stride={self.stride})")
+
+    def _x3_layer(self, x_shape, Co) -> bool:
+        """fp32x3 mode: does this conv block (NHWC input shape, output channels) run on the split kernels?"""
+        return self.x3 and len(x_shape) == 4 and ops.conv_x3_supported(x_shape[1], x_shape[2], x_shape[3], Co, self.stride)
 
     def _side_streams(self, dev):
         # VQA_STREAMS: 0 = one stream; 1 = the question branch on a side stream, joined before the image branch;
@@ -220,7 +227,8 @@ class Engine:
                 wds.append(wdT)
                 continue
             wf, wd = ops.conv_pack_weights(w, acts[-1].shape[3], need_wd=(keep and l > 0))
-            pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l)
+            pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l,
+                                      x3=self._x3_layer(acts[-1].shape, w.shape[0]))
             acts.append(pooled)
             idxs.append(am)
             wds.append(wd)
@@ -467,9 +475,10 @@ class Engine:
                                     self.stride, tag=l)
                 dP = ops.conv_dgrad_bf16(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride, tag=l)
                 continue
+            x3 = self._x3_layer(ctx.acts[l].shape, dP.shape[3])
             ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
-                           self.stride, tag=l)
+                           self.stride, tag=l, x3=x3)
             if l > 0:
-                dP = ops.conv_dgrad(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride, tag=l)
+                dP = ops.conv_dgrad(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride, tag=l, x3=x3)
         ready("image")
         main.wait_event(ev0)

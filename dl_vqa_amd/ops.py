@@ -66,6 +66,13 @@ def conv_out_hw(H: int, W: int, stride: int) -> Tuple[int, int]:
     return ((H - 3) // stride + 1) // 2, ((W - 3) // stride + 1) // 2
 
 
+def x3_split(x: torch.Tensor):
+    """The exact three-way bf16 split of the fp32x3 kernels: x (fp32, numel % 4 == 0) -> (hi, mid, lo) bf16."""
+    out = [torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) for _ in range(3)]
+    call("vqa_x3_split", ptr(x), ptr(out[0]), ptr(out[1]), ptr(out[2]), x.numel(), stream())
+    return out
+
+
 def conv_x3_supported(H: int, W: int, CiP: int, Co: int, stride: int) -> bool:
     return bool(_lib.load().vqa_conv3x3_x3_supported(H, W, CiP, Co, stride))
 

@@ -310,6 +310,8 @@ int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* ar
  * vqa_conv3x3_dgrad / vqa_conv3x3_wgrad (models/model.py:72-84); shapes: CiP, Co multiples of 32 and a conv output
  * row of at least 32 pixels (vqa_conv3x3_x3_supported), other layers keep the fp32 MFMA entry points. */
 int vqa_conv3x3_x3_supported(int H, int W, int CiP, int Co, int stride);
+/* the operand split of those kernels on its own (tests): x[n] -> three planes of n bf16, x == hi + mid + lo exactly */
+int vqa_x3_split(const float* x, void* hi, void* mid, void* lo, int64_t n /* multiple of 4 */, vqa_stream_t stream);
 int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* argmax,
                                  int B, int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream);
 int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const float* wd, float* dx, int B, int H, int W,

@@ -25,6 +25,23 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
+def test_split_is_exact():
+    """x == hi + mid + lo exactly (float64 sum of the three bf16 terms), hi = RNE(x), |mid| <= 2^-8 |hi|, |lo| <= 2^-16 |hi|:
+    random values over 60 binades, powers of two, values that round up to the next binade, zeros, both signs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1 << 16, generator=g) * torch.exp2(torch.randint(-30, 30, (1 << 16,), generator=g).float())
+    special = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.9999999, 0.99999994, 3.0e38, -3.0e38, 1e-30, 255.99998, 65535.996, 1.00390625])
+    x[:special.numel()] = special
+    hi, mid, lo = ops.x3_split(x.to(DEV))
+    torch.cuda.synchronize()
+    hi, mid, lo = hi.cpu(), mid.cpu(), lo.cpu()
+    assert torch.equal(hi, x.to(torch.bfloat16))
+    assert torch.equal(hi.double() + mid.double() + lo.double(), x.double())
+    assert bool((mid.double().abs() <= hi.double().abs() * 2.0 ** -8).all())
+    assert bool((lo.double().abs() <= hi.double().abs() * 2.0 ** -16).all())
+
+
 X3_CASES = [  # B, H, W, Ci, Co, stride
     (2, 58, 58, 64, 128, 1),   # conv1 family: 192x128 tiles forward / wgrad, 256x64 dgrad
     (1, 38, 38, 128, 256, 1),  # conv2 family

@@ -1,0 +1,16 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+import torch
+from dl_vqa_amd import ops
+g = torch.Generator().manual_seed(0)
+x = torch.randn(1 << 16, generator=g) * torch.exp2(torch.randint(-30, 30, (1 << 16,), generator=g).float())
+special = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.9999999, 0.99999994, 3.0e38, -3.0e38, 1e-30, 255.99998, 65535.996, 1.00390625])
+x[:special.numel()] = special
+hi, mid, lo = [t.cpu() for t in ops.x3_split(x.cuda())]
+s = hi.double() + mid.double() + lo.double()
+bad = (s != x.double())
+print("hi mismatch", int((hi != x.to(torch.bfloat16)).sum()), "sum mismatch", int(bad.sum()))
+idx = bad.nonzero().flatten()[:10]
+for i in idx:
+    print(i.item(), x[i].item(), hi[i].item(), mid[i].item(), lo[i].item(), (s[i] - x[i].double()).item())
+print("mid bound viol", int((mid.double().abs() > hi.double().abs() * 2.0 ** -8).sum()), "lo bound viol", int((lo.double().abs() > hi.double().abs() * 2.0 ** -16).sum()))

@@ -21,7 +21,7 @@ using CfgXn = TileCfg<256, 64, 4, 1, 4, VQA_X3_PF>;      // 64 output columns (c
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename ConvFwdA<Cfg::NVA, Cfg::LT, true>::Params pa,
-                                                                      typename PlainC<Cfg::NVB, Cfg::LT>::Params pb,
+                                                                      typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
                                                                       const float* __restrict__ bias, float* pooled,
                                                                       uint8_t* amax, int Co, int tiles_m, int tiles_n, int nk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename C
   const TileCoord tc = tile_coord(tiles_m, tiles_n);
   const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
   using AL = ConvFwdA<Cfg::NVA, Cfg::LT, true>;
-  using BL = PlainC<Cfg::NVB, Cfg::LT>;
+  using BL = PlainCx<Cfg::NVB, Cfg::LT>;
   f32x16 acc[Cfg::TM][Cfg::TN];
   acc_zero<Cfg>(acc);
   if (!gemm_mainloop_x<Cfg, AL, BL>(
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename C
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename ConvDgradA<Cfg::NVA, Cfg::LT, true>::Params pa,
-                                                                        typename PlainC<Cfg::NVB, Cfg::LT>::Params pb,
+                                                                        typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
                                                                         float* dx, int CiP, int tiles_m, int tiles_n, int nk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename
   const TileCoord tc = tile_coord(tiles_m, tiles_n);
   const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
   using AL = ConvDgradA<Cfg::NVA, Cfg::LT, true>;
-  using BL = PlainC<Cfg::NVB, Cfg::LT>;
+  using BL = PlainCx<Cfg::NVB, Cfg::LT>;
   f32x16 acc[Cfg::TM][Cfg::TN];
   acc_zero<Cfg>(acc);
   if (!gemm_mainloop_x<Cfg, AL, BL>(
@@ -94,12 +94,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename
 }
 
 template <class Cfg>
-static int launch_fwd_x3(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* amax,
+static int launch_fwd_x3(const float* x, const void* wf, const float* bias, float* pooled, uint8_t* amax,
                          const ConvGeom& g, hipStream_t s) {
   using SL = SmemLayoutX<Cfg, true, false>;
   const int nWin = g.B * g.Hp * g.Wp, K = 9 * g.CiP;
   typename ConvFwdA<Cfg::NVA, Cfg::LT, true>::Params pa{x, g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
-  typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wf, g.Co, g.Co, K};
+  typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb{wf, g.Co, g.Co, K, (int64_t)K * g.Co};
   const int tiles_m = (4 * nWin + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.Co + Cfg::BN - 1) / Cfg::BN;
   auto kern = conv_fwd_x3_kernel<Cfg>;
   { int rc = set_smem(kern, SL::BYTES, "attr(conv_fwd_x3)"); if (rc) return rc; }
@@ -109,12 +109,12 @@ static int launch_fwd_x3(const float* x, const float* wf, const float* bias, flo
 }
 
 template <class Cfg>
-static int launch_dgrad_x3(const float* dp, const uint8_t* am, const float* wd, float* dx, const ConvGeom& g,
+static int launch_dgrad_x3(const float* dp, const uint8_t* am, const void* wd, float* dx, const ConvGeom& g,
                            hipStream_t s) {
   using SL = SmemLayoutX<Cfg, true, false>;
   const int rows = g.B * g.H * g.W, K = 9 * g.Co;
   typename ConvDgradA<Cfg::NVA, Cfg::LT, true>::Params pa{dp, am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
-  typename PlainC<Cfg::NVB, Cfg::LT>::Params pb{wd, g.CiP, g.CiP, K};
+  typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb{wd, g.CiP, g.CiP, K, (int64_t)K * g.CiP};
   const int tiles_m = (rows + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.CiP + Cfg::BN - 1) / Cfg::BN;
   auto kern = conv_dgrad_x3_kernel<Cfg>;
   { int rc = set_smem(kern, SL::BYTES, "attr(conv_dgrad_x3)"); if (rc) return rc; }
@@ -167,7 +167,7 @@ int vqa_conv3x3_x3_supported(int H, int W, int CiP, int Co, int stride) {
   return (g.Hp > 0 && g.Wp > 0 && x3_conv_ok(CiP, Co, g.Wp)) ? 1 : 0;
 }
 
-int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* argmax,
+int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const void* wf, const float* bias, float* pooled, uint8_t* argmax,
                                  int B, int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
   VQA_REQUIRE(x && wf && bias && pooled && argmax && B > 0, "vqa_conv3x3_relu_pool_fwd_x3: null pointer");
   VQA_REQUIRE(CiP % BK == 0, "vqa_conv3x3_relu_pool_fwd_x3: CiP=%d must be a multiple of %d", CiP, BK);
@@ -189,7 +189,7 @@ int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const float* wf, const float* b
   return VQA_OK;
 }
 
-int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const float* wd, float* dx, int B, int H, int W,
+int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const void* wd, float* dx, int B, int H, int W,
                          int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
   VQA_REQUIRE(dpooled && argmax && wd && dx && B > 0, "vqa_conv3x3_dgrad_x3: null pointer");
   VQA_REQUIRE(Co % BK == 0, "vqa_conv3x3_dgrad_x3: Co=%d must be a multiple of %d", Co, BK);

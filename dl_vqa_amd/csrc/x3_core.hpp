@@ -78,6 +78,47 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, ui
 #endif
 }
 
+// ---------------------------------------------------------------- operands split ahead of time
+// A loader may deliver its chunks already split (weights: split once per step by vqa_x3_split instead of by every
+// workgroup in every K-step).  Such a loader has kPreSplit = true and planes(raw, p, hi, mid, lo) instead of finish().
+template <class L, class = void> struct is_presplit : std::false_type {};
+template <class L> struct is_presplit<L, std::void_t<decltype(L::kPreSplit)>> : std::bool_constant<L::kPreSplit> {};
+
+// Type C over a pre-split row-major matrix: three planes X_hi, X_mid, X_lo [K][cols] of bf16, `plane` elements apart.
+// Thread -> (k row, 4-column chunks) as PlainC; a chunk is one 8-byte load per plane.  cols, ld multiples of 4.
+template <int NV, int LT = 256>
+struct PlainCx {
+  struct Params { const void* p; int64_t ld; int cols; int K; int64_t plane; };
+  struct Raw { uint2 v[NV][3]; };
+  static constexpr bool kTypeR = false;
+  static constexpr bool kPreSplit = true;
+  const char* base;
+  int64_t ldb, planeb;
+  uint32_t voff[NV];
+  int K, kr;
+  __device__ __forceinline__ void init(const Params& q, int col0, int tid, int /*ks0*/) {
+    K = q.K; kr = StageMap<LT>::c_krow(tid); ldb = q.ld * 2; planeb = q.plane * 2;
+    base = reinterpret_cast<const char*>(q.p) + (int64_t)col0 * 2;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int cl = 4 * StageMap<LT>::c_chunk(tid, p);
+      voff[p] = col0 + cl < q.cols ? (uint32_t)(kr * (int)q.ld + cl) * 2u : BUF_OOB;
+    }
+  }
+  __device__ __forceinline__ void issue(int ks, Raw& r) {
+    const bool rowok = kr < K - ks * BK;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = buf_rsrc(base + pl * planeb + (int64_t)ks * BK * ldb);
+#pragma unroll
+      for (int p = 0; p < NV; ++p) r.v[p][pl] = buf_load8(rs, rowok ? voff[p] : BUF_OOB);
+    }
+  }
+  __device__ __forceinline__ void planes(const Raw& r, int p, uint2& hi, uint2& mid, uint2& lo) const {
+    hi = r.v[p][0]; mid = r.v[p][1]; lo = r.v[p][2];
+  }
+};
+
 // ---------------------------------------------------------------- loader role
 template <class Cfg, class L, bool IS_A>
 __device__ __forceinline__ void stage_store_x(const L& ld, const typename L::Raw& raw, float* dst, int ltid,
@@ -85,12 +126,16 @@ __device__ __forceinline__ void stage_store_x(const L& ld, const typename L::Raw
   constexpr int NV = IS_A ? Cfg::NVA : Cfg::NVB;
   constexpr int TILE = IS_A ? Cfg::BM : Cfg::BN;
   float4 r[NV];
-  ld.finish(raw, r);
+  if constexpr (!is_presplit<L>::value) ld.finish(raw, r);
   char* const d = reinterpret_cast<char*>(dst);
 #pragma unroll
   for (int p = 0; p < NV; ++p) {
     uint2 h, m, l;
-    split4(r[p], h, m, l, k);
+    if constexpr (is_presplit<L>::value) ld.planes(raw, p, h, m, l); else split4(r[p], h, m, l, k);
+#ifdef VQA_X3_EXP_NOWRITE   // timing experiment: loads + split, no LDS writes
+    asm volatile("" ::"v"(h.x), "v"(h.y), "v"(m.x), "v"(m.y), "v"(l.x), "v"(l.y));
+    continue;
+#endif
     if constexpr (L::kTypeR) {
       char* q = d + (StageMap<Cfg::LT>::r_row(ltid, p) * XRS + 2 * StageMap<Cfg::LT>::r_chunk(ltid)) * 4;
       *reinterpret_cast<uint2*>(q) = h;
@@ -131,9 +176,13 @@ __device__ __forceinline__ void loader_loop_x(AL& al, BL& bl, int ks0, int ks1, 
       if (ks + d < ks1) {
         const int nxt = ((ks + d - ks0) & 1) ^ 1;
         stage_store_x<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid, kc);
+#ifndef VQA_X3_EXP_NOLOAD   // timing experiment: the same registers are split and stored again, no global loads
         al.issue(ks + d + 1 + D, rawA[d]);
+#endif
         stage_store_x<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid, kc);
+#ifndef VQA_X3_EXP_NOLOAD
         bl.issue(ks + d + 1 + D, rawB[d]);
+#endif
         __syncthreads();
       }
     }
@@ -162,9 +211,12 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
   const char* const Bs0 = sm + 2 * SL::ABUF * 4 + b_off;
   bf16x8 a[2][3][Cfg::TM], b[2][3][Cfg::TN];
   auto trread = [](const char* p) -> s16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p)); };
-  auto fetch = [&](const char* ap, const char* bp, int m, int buf) {
+  // fragment reads of one group, A part and B part separately: each part stays below the 15 operations lgkmcnt can
+  // count, so the wait in front of an MFMA block covers exactly the reads it consumes (with all 21 reads of a group
+  // issued at once the compiler had to wait for the 7 oldest of the NEW reads too: ~200 exposed cycles per group)
+  auto fetchA = [&](const char* ap, int m, int buf) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i) {
         if (AR) {
@@ -176,6 +228,10 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
           a[buf][pl][i] = __builtin_bit_cast(bf16x8, v);
         }
       }
+  };
+  auto fetchB = [&](const char* bp, int m, int buf) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) {
         if (BR) {
@@ -187,34 +243,54 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
           b[buf][pl][j] = __builtin_bit_cast(bf16x8, v);
         }
       }
-    }
   };
-  // plane pairs, small terms first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); consecutive MFMAs go to
+  // plane pairs, small terms first: (lo,hi) (hi,lo) (mid,mid) | (mid,hi) (hi,mid) (hi,hi); consecutive MFMAs go to
   // different accumulators
-  auto mma = [&](int buf) {
+  auto mma = [&](int buf, auto half) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int H = decltype(half)::value;
+#ifdef VQA_X3_EXP_NPROD     // timing experiment: only the last NPROD partial products
+    constexpr int T0 = 6 - VQA_X3_EXP_NPROD;
+#else
+    constexpr int T0 = 0;
+#endif
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 3 * H; t < 3 * H + 3; ++t) {
+      if (t < T0) continue;
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[buf][PA[t]][i], b[buf][PB[t]][j], acc[i][j], 0, 0, 0);
+    }
   };
+  constexpr std::integral_constant<int, 0> H0{};
+  constexpr std::integral_constant<int, 1> H1{};
   __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
   __syncthreads();
-  fetch(As0, Bs0, 0, 0);
+  fetchA(As0, 0, 0);
+  fetchB(Bs0, 0, 0);
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;
-    fetch(As0 + cur * SL::ABUF * 4, Bs0 + cur * SL::BBUF * 4, 1, 1);
+    const char* const Ac = As0 + cur * SL::ABUF * 4;
+    const char* const Bc = Bs0 + cur * SL::BBUF * 4;
+    fetchA(Ac, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma(0);
+    mma(0, H0);
+    __builtin_amdgcn_sched_barrier(0);
+    fetchB(Bc, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, H1);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();   // every fragment of this stage is in registers; the next stage is complete
-    if (ks + 1 < ks1) fetch(As0 + (cur ^ 1) * SL::ABUF * 4, Bs0 + (cur ^ 1) * SL::BBUF * 4, 0, 0);
+    if (ks + 1 < ks1) fetchA(As0 + (cur ^ 1) * SL::ABUF * 4, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    mma(1);
+    mma(1, H0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < ks1) fetchB(Bs0 + (cur ^ 1) * SL::BBUF * 4, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, H1);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

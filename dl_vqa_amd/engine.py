@@ -227,8 +227,10 @@ class Engine:
                 wds.append(wdT)
                 continue
             wf, wd = ops.conv_pack_weights(w, acts[-1].shape[3], need_wd=(keep and l > 0))
-            pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l,
-                                      x3=self._x3_layer(acts[-1].shape, w.shape[0]))
+            x3 = self._x3_layer(acts[-1].shape, w.shape[0])
+            if x3:      # the weights are split once per step, not by every workgroup in every K-step
+                wf, wd = ops.x3_split(wf), (ops.x3_split(wd) if wd is not None else None)
+            pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l, x3=x3)
             acts.append(pooled)
             idxs.append(am)
             wds.append(wd)

@@ -66,9 +66,10 @@ def conv_out_hw(H: int, W: int, stride: int) -> Tuple[int, int]:
     return ((H - 3) // stride + 1) // 2, ((W - 3) // stride + 1) // 2
 
 
-def x3_split(x: torch.Tensor):
-    """The exact three-way bf16 split of the fp32x3 kernels: x (fp32, numel % 4 == 0) -> (hi, mid, lo) bf16."""
-    out = [torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) for _ in range(3)]
+def x3_split(x: torch.Tensor) -> torch.Tensor:
+    """The exact three-way bf16 split of the fp32x3 kernels: x (fp32, numel % 4 == 0) -> planes [3, *x.shape] bf16
+    (hi, mid, lo) with x == hi + mid + lo."""
+    out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
     call("vqa_x3_split", ptr(x), ptr(out[0]), ptr(out[1]), ptr(out[2]), x.numel(), stream())
     return out
 
@@ -79,9 +80,10 @@ def conv_x3_supported(H: int, W: int, CiP: int, Co: int, stride: int) -> bool:
 
 def conv_fwd(x: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False):
     """x NHWC [B,H,W,CiP] -> (pooled [B,Hp,Wp,Co], argmax uint8 same shape).  x3: fp32 on the bf16 matrix cores
-    (exact 3 x bf16 operand split, csrc/x3_core.hpp) instead of the fp32 MFMA."""
+    (exact 3 x bf16 operand split, csrc/x3_core.hpp) instead of the fp32 MFMA; wf is then x3_split(packed weights)."""
     B, H, W, CiP = x.shape
-    Co = wf.shape[1]
+    Co = wf.shape[-1]
+    assert (wf.dtype == torch.bfloat16 and wf.dim() == 3) if x3 else wf.dtype == torch.float32
     Hp, Wp = conv_out_hw(H, W, stride)
     pooled = torch.empty(B, Hp, Wp, Co, dtype=torch.float32, device=x.device)
     amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x.device)
@@ -93,6 +95,7 @@ def conv_fwd(x: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor, stride: int 
 def conv_dgrad(dpooled, amax, wd, x_shape, stride: int = 1, tag: int = 0, out=None, x3: bool = False) -> torch.Tensor:
     B, H, W, CiP = x_shape
     Co = dpooled.shape[3]
+    assert (wd.dtype == torch.bfloat16 and wd.dim() == 3) if x3 else wd.dtype == torch.float32
     dx = out if out is not None else torch.empty(B, H, W, CiP, dtype=torch.float32, device=dpooled.device)
     call("vqa_conv3x3_dgrad_x3" if x3 else "vqa_conv3x3_dgrad", ptr(dpooled), ptr(amax), ptr(wd), ptr(dx), B, H, W, CiP,
          Co, stride, tag, stream())

@@ -306,15 +306,17 @@ int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* ar
  * fp32 operand element is split exactly into three bf16 terms (8 + 8 + 8 significand bits) and a product is
  * accumulated in fp32 from its six partial products of weight >= 2^-16 (the dropped ones are below 2^-24 of the
  * product, less than one fp32 rounding): six v_mfma_f32_32x32x16_bf16 instead of eight v_mfma_f32_32x32x2_f32 per
- * 32x32x16 block, 2.67x the fp32 MFMA rate at fp32 accuracy.  Arguments exactly as vqa_conv3x3_relu_pool_fwd /
- * vqa_conv3x3_dgrad / vqa_conv3x3_wgrad (models/model.py:72-84); shapes: CiP, Co multiples of 32 and a conv output
+ * 32x32x16 block, 2.67x the fp32 MFMA rate at fp32 accuracy.  Arguments as vqa_conv3x3_relu_pool_fwd /
+ * vqa_conv3x3_dgrad / vqa_conv3x3_wgrad (models/model.py:72-84), except that the packed weights wf / wd are handed over
+ * already split: three bf16 planes (hi, mid, lo), each in the layout of vqa_conv_pack_weights and one after the other
+ * (vqa_x3_split of the fp32 packing, once per step); shapes: CiP, Co multiples of 32 and a conv output
  * row of at least 32 pixels (vqa_conv3x3_x3_supported), other layers keep the fp32 MFMA entry points. */
 int vqa_conv3x3_x3_supported(int H, int W, int CiP, int Co, int stride);
 /* the operand split of those kernels on its own (tests): x[n] -> three planes of n bf16, x == hi + mid + lo exactly */
 int vqa_x3_split(const float* x, void* hi, void* mid, void* lo, int64_t n /* multiple of 4 */, vqa_stream_t stream);
-int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const float* wf, const float* bias, float* pooled, uint8_t* argmax,
+int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const void* wf_planes, const float* bias, float* pooled, uint8_t* argmax,
                                  int B, int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream);
-int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const float* wd, float* dx, int B, int H, int W,
+int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const void* wd_planes, float* dx, int B, int H, int W,
                          int CiP, int Co, int stride, int tag, vqa_stream_t stream);
 int64_t vqa_conv3x3_wgrad_x3_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride);
 int vqa_conv3x3_wgrad_x3(const float* x, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B,

@@ -33,9 +33,8 @@ def test_split_is_exact():
     x = torch.randn(1 << 16, generator=g) * torch.exp2(torch.randint(-30, 30, (1 << 16,), generator=g).float())
     special = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.9999999, 0.99999994, 3.0e38, -3.0e38, 1e-30, 255.99998, 65535.996, 1.00390625])
     x[:special.numel()] = special
-    hi, mid, lo = ops.x3_split(x.to(DEV))
+    hi, mid, lo = ops.x3_split(x.to(DEV)).cpu()
     torch.cuda.synchronize()
-    hi, mid, lo = hi.cpu(), mid.cpu(), lo.cpu()
     assert torch.equal(hi, x.to(torch.bfloat16))
     assert torch.equal(hi.double() + mid.double() + lo.double(), x.double())
     assert bool((mid.double().abs() <= hi.double().abs() * 2.0 ** -8).all())
@@ -67,15 +66,16 @@ def test_conv_x3_matches_float64_like_native_fp32(B, H, W, Ci, Co, stride):
 
     xd = _nhwc(x).to(DEV)
     wf, wd = ops.conv_pack_weights(w.to(DEV), Ci)
+    wfx, wdx = ops.x3_split(wf), ops.x3_split(wd)
     dyd = _nhwc(dy).to(DEV)
     tag = f"{B,H,W,Ci,Co,stride}"
     res = {}
     for x3 in (False, True):
-        pooled, amax = ops.conv_fwd(xd, wf, b.to(DEV), stride, x3=x3)
+        pooled, amax = ops.conv_fwd(xd, wfx if x3 else wf, b.to(DEV), stride, x3=x3)
         # the backward kernels of both paths get the SAME arg-max bytes (a pre-activation tie broken differently by
         # rounding would compare different functions)
         am = amax if not x3 else res[False][1]
-        dx = ops.conv_dgrad(dyd, am, wd, xd.shape, stride, x3=x3)
+        dx = ops.conv_dgrad(dyd, am, wdx if x3 else wd, xd.shape, stride, x3=x3)
         dw, db = torch.empty(Co, Ci, 3, 3, device=DEV), torch.empty(Co, device=DEV)
         ops.conv_wgrad(xd, dyd, am, dw, db, stride, x3=x3)
         torch.cuda.synchronize()

@@ -6,7 +6,7 @@ g = torch.Generator().manual_seed(0)
 x = torch.randn(1 << 16, generator=g) * torch.exp2(torch.randint(-30, 30, (1 << 16,), generator=g).float())
 special = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.9999999, 0.99999994, 3.0e38, -3.0e38, 1e-30, 255.99998, 65535.996, 1.00390625])
 x[:special.numel()] = special
-hi, mid, lo = [t.cpu() for t in ops.x3_split(x.cuda())]
+hi, mid, lo = ops.x3_split(x.cuda()).cpu()
 s = hi.double() + mid.double() + lo.double()
 bad = (s != x.double())
 print("hi mismatch", int((hi != x.to(torch.bfloat16)).sum()), "sum mismatch", int(bad.sum()))

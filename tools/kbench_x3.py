@@ -38,14 +38,15 @@ def main():
         w = torch.randn(Co, Ci, 3, 3, device=dev) * (1.0 / (9 * Ci) ** 0.5)
         b = torch.zeros(Co, device=dev)
         wf, wd = ops.conv_pack_weights(w, Ci)
+        wfx, wdx = ops.x3_split(wf), ops.x3_split(wd)
         Ho = x.shape[1] - 2
         flops = 2.0 * B * Ho * Ho * Co * 9 * Ci
         pooled, am = ops.conv_fwd(x, wf, b, 1)
         dp = torch.randn_like(pooled)
         dw, db = torch.empty_like(w), torch.empty_like(b)
         dx = torch.empty_like(x)
-        for name, fn in (("fwd", lambda x3: ops.conv_fwd(x, wf, b, 1, x3=x3)),
-                         ("dgrad", lambda x3: ops.conv_dgrad(dp, am, wd, x.shape, 1, out=dx, x3=x3)),
+        for name, fn in (("fwd", lambda x3: ops.conv_fwd(x, wfx if x3 else wf, b, 1, x3=x3)),
+                         ("dgrad", lambda x3: ops.conv_dgrad(dp, am, wdx if x3 else wd, x.shape, 1, out=dx, x3=x3)),
                          ("wgrad", lambda x3: ops.conv_wgrad(x, dp, am, dw, db, 1, x3=x3))):
             t = {x3: timeit(lambda: fn(x3), args.iters) for x3 in (False, True)}
             tf = {k: flops / v / 1e9 for k, v in t.items()}

@@ -14,7 +14,7 @@
 //             loads); each wave keeps its 32 x Co partial dW in accumulators for its whole lifetime and
 //             writes ONE slab at the end (deterministic two-level reduction, no atomics).
 // LDS row strides are chosen per kernel so that the 32 lanes of a fragment read hit 32 different banks.
-#include "bf16_core.hpp"
+#include "x3_core.hpp"
 
 namespace vqa {
 
@@ -35,8 +35,8 @@ __host__ __device__ inline int c0_round_stride(int W, int want_mod) {
 constexpr int C0_FR = 4;
 constexpr int C0_PR = 2 * C0_FR + 2;
 
-// OB: pooled is stored as bf16 (the bf16 path's P_0) instead of fp32
-template <int CI, int TN, bool OB>
+// OB: 0 = pooled is stored as fp32, 1 = as bf16 (the bf16 path's P_0), 2 = x3-packed (the fp32x3 path: vqa_x3_pack's form)
+template <int CI, int TN, int OB>
 __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, void* pooled_, uint8_t* amax,
                                                         int H, int W, int Hp, int Wp, int RS) {
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restri
   const int nwin = nwr * Wp, ntiles = (nwin + 7) / 8;
   // windows of the workgroup are consecutive in memory: offset = first window + wo * Co
   const int64_t o0 = (int64_t)(b * Hp + py0) * Wp * Co;
-  const __amdgpu_buffer_rsrc_t rp = OB ? buf_rsrc(pooled16 + o0) : buf_rsrc(pooled + o0), ra = buf_rsrc(amax + o0);
+  const __amdgpu_buffer_rsrc_t rp = OB == 2 ? buf_rsrc(pooled16 + 3 * o0) : OB == 1 ? buf_rsrc(pooled16 + o0) : buf_rsrc(pooled + o0),
+                               ra = buf_rsrc(amax + o0);
   for (int t = wave; t < ntiles; t += 4) {
     // A rows: row i = 4*window + pixel (the engine's window-in-4-registers layout)
     int wdx = 8 * t + (l31 >> 2);
@@ -111,7 +112,14 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restri
         if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
         best += bv[j];
         const uint32_t so = (uint32_t)(2 * g * Co + 32 * j);
-        if (OB) buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl : BUF_OOB, 2u * so);
+        if (OB == 2) {
+          uint16_t sh, sm, sl;
+          split1(best > 0.f ? best : 0.f, sh, sm, sl);
+          const uint32_t vx = ok ? 6u * (uint32_t)__mul24(8 * t + h, Co) + x3p_lane(l31) : BUF_OOB;
+          buf_store2(rp, sh, vx, 6u * so);
+          buf_store2(rp, sm, vx, 6u * so + 8u);
+          buf_store2(rp, sl, vx, 6u * so + 16u);
+        } else if (OB == 1) buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl : BUF_OOB, 2u * so);
         else buf_store4(rp, best > 0.f ? best : 0.f, ok ? 4u * vl : BUF_OOB, 4u * so);
         buf_store1(ra, best > 0.f ? (uint8_t)a : (uint8_t)4, ok ? vl : BUF_OOB, so);
       }
@@ -494,7 +502,7 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
                            argmax, H, W, Hp, Wp, RS);
       }
     });
-  } else if (pooled_is_bf16) { C0_FWD_LAUNCH(true); } else { C0_FWD_LAUNCH(false); }
+  } else if (pooled_is_bf16 == 3) { C0_FWD_LAUNCH(2); } else if (pooled_is_bf16) { C0_FWD_LAUNCH(1); } else { C0_FWD_LAUNCH(0); }
 #undef C0_FWD_LAUNCH
   return check_hip(hipGetLastError(), "conv0_fwd launch");
 }

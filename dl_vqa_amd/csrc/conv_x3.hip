@@ -19,17 +19,178 @@ int64_t colsum_ws_bytes(int64_t rows, int cols);
 using CfgX = TileCfg<192, 128, 2, 2, 4, VQA_X3_PF>;      // MFMA waves of 96 x 64
 using CfgXn = TileCfg<256, 64, 4, 1, 4, VQA_X3_PF>;      // 64 output columns (conv1 dgrad): MFMA waves of 64 x 64
 
+// ------------------------------------------------------------------ activations split ahead of time ("x3-packed")
+// An activation tensor [pixels][C] (C % 4 == 0) can be handed over already split, so that the split is done once per
+// tensor (vqa_x3_pack) instead of by every workgroup that reads it (9 taps x column tiles in forward, row tiles in
+// wgrad).  Layout: every group of four consecutive channels is 24 bytes, hi[4] mid[4] lo[4] bf16 -- element e lives at
+// byte (e / 4) * 24, a pixel's channels stay contiguous (6 bytes per element), and a loader thread's 4-element chunk is
+// one 16-byte + one 8-byte load and three ds_write_b64 without any VALU work.  The loaders below are ConvFwdA<UT> and
+// WgradA<uniform> with every byte offset scaled by 6 / 4.
+template <int NV, int LT>
+struct ConvFwdAx {
+  struct Params { const void* x; int H, W, CiP, Hp, Wp, stride, nWin, K; };
+  struct Raw { float4 a[NV]; uint2 b[NV]; };
+  static constexpr bool kTypeR = true;
+  static constexpr bool kPreSplit = true;
+  const char* x;
+  uint32_t voff[NV];
+  int W, CiP;
+  TapCursor cur;
+  __device__ __forceinline__ void init(const Params& q, int row0, int tid, int ks0) {
+    x = static_cast<const char*>(q.x); W = q.W; CiP = q.CiP;
+    const int c4 = 4 * StageMap<LT>::r_chunk(tid);
+    cur.init(ks0 * BK, q.CiP);
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int m = row0 + StageMap<LT>::r_row(tid, p);
+      const int wl = m >> 2, j = m & 3;
+      const int px = wl % q.Wp;
+      const int t = wl / q.Wp;
+      const int py = t % q.Hp;
+      const int b = t / q.Hp;
+      const int y = (2 * py + (j >> 1)) * q.stride, xx = (2 * px + (j & 1)) * q.stride;
+      const uint32_t e = (uint32_t)((b * q.H + y) * q.W + xx) * (uint32_t)q.CiP + (uint32_t)c4;
+      voff[p] = wl < q.nWin ? e * 6u : BUF_OOB;
+    }
+  }
+  __device__ __forceinline__ void issue(int /*ks*/, Raw& r) {
+    const bool kok = cur.tap < 9;
+    const int tap = kok ? cur.tap : 0;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const int koff = (ky * W + kx) * CiP + cur.ch;
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(x + (int64_t)koff * 6, kok ? BUF_OOB : 0u);
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      r.a[p] = buf_load16(rs, voff[p]);
+      r.b[p] = buf_load8(rs, voff[p], 16);
+    }
+    cur.advance();
+  }
+  __device__ __forceinline__ void planes(const Raw& r, int p, uint2& hi, uint2& mid, uint2& lo) const {
+    hi = make_uint2(__float_as_uint(r.a[p].x), __float_as_uint(r.a[p].y));
+    mid = make_uint2(__float_as_uint(r.a[p].z), __float_as_uint(r.a[p].w));
+    lo = r.b[p];
+  }
+};
+
+template <int NV, int LT>
+struct WgradAx {   // A(i = (ky,kx,ci), m) = x[b][yo*s+ky][xo*s+kx][ci], x3-packed
+  struct Params { const void* x; WgradGeom g; int KI; };
+  struct Raw { float4 a[NV]; uint2 b[NV]; };
+  static constexpr bool kTypeR = false;
+  static constexpr bool kPreSplit = true;
+  Params q;
+  uint32_t su[NV];
+  uint32_t lp0, lp1;
+  uint32_t pix, row, img, fix_img;
+  int kr;
+  RowCursor rc;
+  __device__ __forceinline__ void init(const Params& q_, int i0, int tid, int ks0) {
+    q = q_;
+    kr = StageMap<LT>::c_krow(tid);
+    const int hw = __builtin_amdgcn_readfirstlane(tid >> 8);
+    rc.init(ks0 * BK, q.g.Hp, q.g.Wp);
+    pix = (uint32_t)(q.g.stride * q.g.CiP) * 6u; row = (uint32_t)q.g.W * pix;
+    img = (uint32_t)(q.g.H * q.g.W * q.g.CiP) * 6u;
+    fix_img = img - (uint32_t)rc.Ho2 * row;
+    lp0 = (uint32_t)kr * pix + 24u * (uint32_t)(tid & 7);
+    lp1 = lp0 + row - (uint32_t)rc.Wo2 * pix;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int i = i0 + BK * (hw + (LT / 256) * p);
+      const int ii = i < q.KI ? i : 0;
+      const int tap = ii / q.g.CiP;
+      const int ci = ii - tap * q.g.CiP;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      su[p] = (uint32_t)((ky * q.g.W + kx) * q.g.CiP + ci) * 6u;
+    }
+  }
+  __device__ __forceinline__ void issue(int ks, Raw& r) {
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(q.x);
+    const int n1 = rc.Wo2 - rc.xs;
+    const uint32_t base = (uint32_t)rc.b * img + (uint32_t)rc.yo * row + (uint32_t)rc.xs * pix;
+    uint32_t l1 = lp1;
+    if (rc.yo + 1 == rc.Ho2 && n1 < BK) l1 += fix_img;
+    const uint32_t off = kr < n1 ? lp0 : l1;
+    if ((ks + 1) * BK <= q.g.Mtot) {
+#pragma unroll
+      for (int p = 0; p < NV; ++p) {
+        r.a[p] = buf_load16(rs, off, base + su[p]);
+        r.b[p] = buf_load8(rs, off, base + su[p] + 16u);
+      }
+    } else {
+      const uint32_t o2 = rc.m0 + kr < q.g.Mtot ? off + base : BUF_OOB;
+#pragma unroll
+      for (int p = 0; p < NV; ++p) {
+        r.a[p] = buf_load16(rs, o2, su[p]);
+        r.b[p] = buf_load8(rs, o2, su[p] + 16u);
+      }
+    }
+    rc.advance();
+  }
+  __device__ __forceinline__ void planes(const Raw& r, int p, uint2& hi, uint2& mid, uint2& lo) const {
+    hi = make_uint2(__float_as_uint(r.a[p].x), __float_as_uint(r.a[p].y));
+    mid = make_uint2(__float_as_uint(r.a[p].z), __float_as_uint(r.a[p].w));
+    lo = r.b[p];
+  }
+};
+
+// conv_pool_epilogue with the pooled activation written in the x3-packed form (the next block's input): bit-identical
+// to vqa_x3_pack of the fp32 output.
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename ConvFwdA<Cfg::NVA, Cfg::LT, true>::Params pa,
+__device__ __forceinline__ void conv_pool_epilogue_x3p(f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* __restrict__ bias,
+                                                       void* pooled_, uint8_t* amax, int nWin, int Co, int m0, int n0,
+                                                       int wm, int wn, int lane) {
+  char* pooled = static_cast<char*>(pooled_);
+  const int h = lane >> 5, l31 = lane & 31;
+  const bool interior = (m0 + Cfg::BM) / 4 <= nWin && n0 + Cfg::BN <= Co;   // uniform
+  const uint32_t vl = (uint32_t)(h * Co + l31);                             // elements (arg-max bytes)
+  const uint32_t vx = 6u * (uint32_t)(h * Co) + x3p_lane(l31);              // bytes (packed activation)
+  auto body = [&](auto inner) {
+    constexpr bool INNER = decltype(inner)::value;
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int colt = n0 + wn * Cfg::WN + 32 * j;
+      const int col = colt + l31;
+      const float bv = INNER || col < Co ? bias[INNER || col < Co ? col : 0] : 0.f;
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        const int wt = (m0 + wm * Cfg::WM + 32 * i) >> 2;                   // tile's first window (uniform)
+        const int64_t o0 = (int64_t)wt * Co + colt;
+        const __amdgpu_buffer_rsrc_t rp = buf_rsrc(pooled + 6 * o0), ra = buf_rsrc(amax + o0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float best = acc[i][j][4 * g];
+          int a = 0;
+          if (acc[i][j][4 * g + 1] > best) { best = acc[i][j][4 * g + 1]; a = 1; }
+          if (acc[i][j][4 * g + 2] > best) { best = acc[i][j][4 * g + 2]; a = 2; }
+          if (acc[i][j][4 * g + 3] > best) { best = acc[i][j][4 * g + 3]; a = 3; }
+          best += bv;
+          const bool ok = INNER || (wt + 2 * g + h < nWin && col < Co);
+          const uint32_t so = (uint32_t)(2 * g * Co);
+          uint16_t sh, sm, sl;
+          split1(best > 0.f ? best : 0.f, sh, sm, sl);
+          buf_store2(rp, sh, ok ? vx : BUF_OOB, 6u * so);
+          buf_store2(rp, sm, ok ? vx : BUF_OOB, 6u * so + 8u);
+          buf_store2(rp, sl, ok ? vx : BUF_OOB, 6u * so + 16u);
+          buf_store1(ra, best > 0.f ? (uint8_t)a : (uint8_t)4, ok ? vl : BUF_OOB, so);
+        }
+      }
+    }
+  };
+  if (interior) body(std::true_type{}); else body(std::false_type{});
+}
+
+template <class Cfg, class AL, bool OP>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename AL::Params pa,
                                                                       typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
-                                                                      const float* __restrict__ bias, float* pooled,
+                                                                      const float* __restrict__ bias, void* pooled,
                                                                       uint8_t* amax, int Co, int tiles_m, int tiles_n, int nk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const TileCoord tc = tile_coord(tiles_m, tiles_n);
   const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
-  using AL = ConvFwdA<Cfg::NVA, Cfg::LT, true>;
   using BL = PlainCx<Cfg::NVB, Cfg::LT>;
   f32x16 acc[Cfg::TM][Cfg::TN];
   acc_zero<Cfg>(acc);
@@ -40,7 +201,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename C
           },
           acc, 0, nk, smem))
     return;
-  conv_pool_epilogue<Cfg>(acc, bias, pooled, amax, pa.nWin, Co, m0, n0, wm, wn, lane);
+  if constexpr (OP) conv_pool_epilogue_x3p<Cfg>(acc, bias, pooled, amax, pa.nWin, Co, m0, n0, wm, wn, lane);
+  else conv_pool_epilogue<Cfg>(acc, bias, pooled, amax, pa.nWin, Co, m0, n0, wm, wn, lane);
 }
 
 template <class Cfg>
@@ -66,8 +228,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename
   store_acc_tiles<Cfg>(acc, dx, CiP, pa.rows, CiP, m0, n0, wm, wn, lane);
 }
 
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename WgradA<Cfg::NVA, Cfg::LT, true>::Params pa,
+template <class Cfg, class AL>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename AL::Params pa,
                                                                         typename WgradB<Cfg::NVB, Cfg::LT, true>::Params pb,
                                                                         float* slab, int tiles_m, int tiles_n, int nk,
                                                                         int ks_per_split) {
@@ -78,7 +240,6 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename
   const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
   const int ks0 = tc.split * ks_per_split;
   const int ks1 = min(nk, ks0 + ks_per_split);
-  using AL = WgradA<Cfg::NVA, Cfg::LT, true>;
   using BL = WgradB<Cfg::NVB, Cfg::LT, true>;
   f32x16 acc[Cfg::TM][Cfg::TN];
   acc_zero<Cfg>(acc);
@@ -93,15 +254,15 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename
   store_acc_tiles<Cfg>(acc, slab + (int64_t)tc.split * pa.KI * Co, Co, pa.KI, Co, m0, n0, wm, wn, lane);
 }
 
-template <class Cfg>
-static int launch_fwd_x3(const float* x, const void* wf, const float* bias, float* pooled, uint8_t* amax,
+template <class Cfg, class AL, bool OP>
+static int launch_fwd_x3(const void* x, const void* wf, const float* bias, void* pooled, uint8_t* amax,
                          const ConvGeom& g, hipStream_t s) {
   using SL = SmemLayoutX<Cfg, true, false>;
   const int nWin = g.B * g.Hp * g.Wp, K = 9 * g.CiP;
-  typename ConvFwdA<Cfg::NVA, Cfg::LT, true>::Params pa{x, g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
+  typename AL::Params pa{static_cast<decltype(AL::Params::x)>(x), g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
   typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb{wf, g.Co, g.Co, K, (int64_t)K * g.Co};
   const int tiles_m = (4 * nWin + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.Co + Cfg::BN - 1) / Cfg::BN;
-  auto kern = conv_fwd_x3_kernel<Cfg>;
+  auto kern = conv_fwd_x3_kernel<Cfg, AL, OP>;
   { int rc = set_smem(kern, SL::BYTES, "attr(conv_fwd_x3)"); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, bias, pooled, amax, g.Co,
                      tiles_m, tiles_n, K / BK);
@@ -146,7 +307,19 @@ __global__ void x3_split_kernel(const float4* x, uint2* hi, uint2* mid, uint2* l
   if (i < n4) split4(x[i], hi[i], mid[i], lo[i], split_consts());
 }
 
+// fp32 [n] -> x3-packed: 24 bytes per 4 elements, hi[4] mid[4] lo[4]
+__global__ void x3_pack_kernel(const float4* x, uint2* out, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  uint2 h, m, l;
+  split4(x[i], h, m, l, split_consts());
+  out[3 * i] = h; out[3 * i + 1] = m; out[3 * i + 2] = l;
+}
+
 static bool x3_conv_ok(int CiP, int Co, int Wp) { return CiP % BK == 0 && Co % BK == 0 && 2 * Wp >= BK; }
+// images per launch: as batch_chunk, with the input tensor at 6 bytes per element (the packed form; also used for
+// fp32 inputs so that the forward / wgrad / workspace computations agree whatever the input form)
+static int x3_chunk(int B, int H, int W, int CiP, int Co, int stride) { return batch_chunk(B, H, W, CiP / 2 * 3, Co, stride); }
 
 }  // namespace vqa
 
@@ -162,16 +335,30 @@ int vqa_x3_split(const float* x, void* hi, void* mid, void* lo, int64_t n, vqa_s
   return check_hip(hipGetLastError(), "x3_split launch");
 }
 
+int vqa_x3_pack(const float* x, void* out, int64_t n, vqa_stream_t stream) {
+  VQA_REQUIRE(x && out && n > 0 && n % 4 == 0, "vqa_x3_pack: bad args (n=%lld must be a multiple of 4)", (long long)n);
+  hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), static_cast<uint2*>(out), n / 4);
+  return check_hip(hipGetLastError(), "x3_pack launch");
+}
+
 int vqa_conv3x3_x3_supported(int H, int W, int CiP, int Co, int stride) {
   const ConvGeom g = make_geom(1, H, W, CiP, Co, stride);
   return (g.Hp > 0 && g.Wp > 0 && x3_conv_ok(CiP, Co, g.Wp)) ? 1 : 0;
 }
 
-int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const void* wf, const float* bias, float* pooled, uint8_t* argmax,
-                                 int B, int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
+int vqa_conv3x3_relu_pool_fwd_x3(const void* x, int x_packed, const void* wf, const float* bias, void* pooled,
+                                 int pooled_packed, uint8_t* argmax, int B, int H, int W, int CiP, int Co, int stride,
+                                 int tag, vqa_stream_t stream) {
   VQA_REQUIRE(x && wf && bias && pooled && argmax && B > 0, "vqa_conv3x3_relu_pool_fwd_x3: null pointer");
   VQA_REQUIRE(CiP % BK == 0, "vqa_conv3x3_relu_pool_fwd_x3: CiP=%d must be a multiple of %d", CiP, BK);
-  const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
+  const int chunk = x3_chunk(B, H, W, CiP, Co, stride);
+  using AF = ConvFwdA<CfgX::NVA, CfgX::LT, true>;
+  using AFn = ConvFwdA<CfgXn::NVA, CfgXn::LT, true>;
+  using AP = ConvFwdAx<CfgX::NVA, CfgX::LT>;
+  using APn = ConvFwdAx<CfgXn::NVA, CfgXn::LT>;
+  const char* xb = static_cast<const char*>(x);
+  const int esz = x_packed ? 6 : 4;
   VQA_REQUIRE(chunk > 0, "vqa_conv3x3_relu_pool_fwd_x3: one %dx%dx%d image reaches 4 GiB", H, W, CiP);
   const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
   set_launch_tag(tag);
@@ -182,8 +369,17 @@ int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const void* wf, const float* bi
     const ConvGeom g = make_geom(nb, H, W, CiP, Co, stride);
     int rc = check_geom("vqa_conv3x3_relu_pool_fwd_x3", g);
     if (rc) return rc;
-    rc = Co > 64 ? launch_fwd_x3<CfgX>(x + xo, wf, bias, pooled + po, argmax + po, g, (hipStream_t)stream)
-                 : launch_fwd_x3<CfgXn>(x + xo, wf, bias, pooled + po, argmax + po, g, (hipStream_t)stream);
+    const void* xc = xb + xo * esz;
+    void* pc = static_cast<char*>(pooled) + po * (pooled_packed ? 6 : 4);
+    hipStream_t st = (hipStream_t)stream;
+#define X3_FWD(CFG, AL, OP) launch_fwd_x3<CFG, AL, OP>(xc, wf, bias, pc, argmax + po, g, st)
+    if (pooled_packed)
+      rc = x_packed ? (Co > 64 ? X3_FWD(CfgX, AP, true) : X3_FWD(CfgXn, APn, true))
+                    : (Co > 64 ? X3_FWD(CfgX, AF, true) : X3_FWD(CfgXn, AFn, true));
+    else
+      rc = x_packed ? (Co > 64 ? X3_FWD(CfgX, AP, false) : X3_FWD(CfgXn, APn, false))
+                    : (Co > 64 ? X3_FWD(CfgX, AF, false) : X3_FWD(CfgXn, AFn, false));
+#undef X3_FWD
     if (rc) return rc;
   }
   return VQA_OK;
@@ -213,8 +409,8 @@ int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const void
 
 int64_t vqa_conv3x3_wgrad_x3_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride) {
   const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
-  if (g1.Hp <= 0 || g1.Wp <= 0 || B <= 0) return 0;
-  const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
+  if (g1.Hp <= 0 || g1.Wp <= 0 || B <= 0 || CiP % BK) return 0;
+  const int chunk = x3_chunk(B, H, W, CiP, Co, stride);
   if (chunk <= 0) return 0;
   int64_t parts = 0;
   for (int b0 = 0; b0 < B; b0 += chunk)
@@ -222,15 +418,15 @@ int64_t vqa_conv3x3_wgrad_x3_workspace_bytes(int B, int H, int W, int CiP, int C
   return parts * (int64_t)9 * CiP * Co * 4 + colsum_ws_bytes((int64_t)B * g1.Hp * g1.Wp, Co);
 }
 
-int vqa_conv3x3_wgrad_x3(const float* x, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B,
-                         int H, int W, int CiP, int Ci, int Co, int stride, float* workspace, int64_t workspace_bytes,
-                         int tag, vqa_stream_t stream) {
+int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, const uint8_t* argmax, float* dw,
+                         float* dbias, int B, int H, int W, int CiP, int Ci, int Co, int stride, float* workspace,
+                         int64_t workspace_bytes, int tag, vqa_stream_t stream) {
   VQA_REQUIRE(x && dpooled && argmax && dw && dbias && workspace && B > 0, "vqa_conv3x3_wgrad_x3: null pointer");
   VQA_REQUIRE(Ci >= 1 && Ci <= CiP, "vqa_conv3x3_wgrad_x3: Ci=%d CiP=%d", Ci, CiP);
   const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
   VQA_REQUIRE(g1.Hp > 0 && g1.Wp > 0 && x3_conv_ok(CiP, Co, g1.Wp),
               "vqa_conv3x3_wgrad_x3: needs CiP, Co multiples of %d and 2*Wp >= %d (CiP=%d Co=%d Wp=%d)", BK, BK, CiP, Co, g1.Wp);
-  const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
+  const int chunk = x3_chunk(B, H, W, CiP, Co, stride);
   VQA_REQUIRE(chunk > 0, "vqa_conv3x3_wgrad_x3: one %dx%dx%d image reaches 4 GiB", H, W, CiP);
   const int64_t need = vqa_conv3x3_wgrad_x3_workspace_bytes(B, H, W, CiP, Co, stride);
   if (workspace_bytes < need) {
@@ -254,14 +450,28 @@ int vqa_conv3x3_wgrad_x3(const float* x, const float* dpooled, const uint8_t* ar
     const WgradPlanX p = plan_wgrad_x3(g);
     using SL = SmemLayoutX<CfgX, false, false>;
     WgradGeom wg{g.H, g.W, g.CiP, g.Hp, g.Wp, g.Co, g.stride, p.Mtot};
-    typename WgradA<CfgX::NVA, CfgX::LT, true>::Params pa{x + (int64_t)b0 * H * W * CiP, wg, p.KI};
     const int64_t po = (int64_t)b0 * g1.Hp * g1.Wp * Co;
     typename WgradB<CfgX::NVB, CfgX::LT, true>::Params pb{dpooled + po, argmax + po, wg};
-    auto kern = conv_wgrad_x3_kernel<CfgX>;
-    rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad_x3)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(CfgX::THREADS), SL::BYTES, s, pa, pb,
-                       workspace + (int64_t)done * KI * Co, p.tiles_m, p.tiles_n, p.nk, p.ks_per_split);
+    const char* xc = static_cast<const char*>(x) + (int64_t)b0 * H * W * CiP * (x_packed ? 6 : 4);
+    const dim3 grid(p.tiles_m * p.tiles_n * p.splits);
+    float* slab = workspace + (int64_t)done * KI * Co;
+    if (x_packed) {
+      using AL = WgradAx<CfgX::NVA, CfgX::LT>;
+      typename AL::Params pa{xc, wg, p.KI};
+      auto kern = conv_wgrad_x3_kernel<CfgX, AL>;
+      rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad_x3p)");
+      if (rc) return rc;
+      hipLaunchKernelGGL(kern, grid, dim3(CfgX::THREADS), SL::BYTES, s, pa, pb, slab, p.tiles_m, p.tiles_n, p.nk,
+                         p.ks_per_split);
+    } else {
+      using AL = WgradA<CfgX::NVA, CfgX::LT, true>;
+      typename AL::Params pa{reinterpret_cast<const float*>(xc), wg, p.KI};
+      auto kern = conv_wgrad_x3_kernel<CfgX, AL>;
+      rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad_x3)");
+      if (rc) return rc;
+      hipLaunchKernelGGL(kern, grid, dim3(CfgX::THREADS), SL::BYTES, s, pa, pb, slab, p.tiles_m, p.tiles_n, p.nk,
+                         p.ks_per_split);
+    }
     rc = check_hip(hipGetLastError(), "conv_wgrad_x3 launch");
     if (rc) return rc;
     done += p.splits;

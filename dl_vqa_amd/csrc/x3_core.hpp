@@ -78,6 +78,16 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, ui
 #endif
 }
 
+// One value at a time (epilogues that write an activation in the x3-packed form): the same three terms as split4.
+__device__ __forceinline__ void split1(float v, uint16_t& h, uint16_t& m, uint16_t& l) {
+  h = bf16_bits(v);
+  const float r1 = v - __uint_as_float((uint32_t)h << 16);
+  m = bf16_bits(r1);
+  l = bf16_bits(r1 - __uint_as_float((uint32_t)m << 16));
+}
+// x3-packed activations (include/vqa_hip.h vqa_x3_pack): byte offset of channel l31 inside its 32-channel group
+__device__ __forceinline__ uint32_t x3p_lane(int l31) { return (uint32_t)((l31 >> 2) * 24 + (l31 & 3) * 2); }
+
 // ---------------------------------------------------------------- operands split ahead of time
 // A loader may deliver its chunks already split (weights: split once per step by vqa_x3_split instead of by every
 // workgroup in every K-step).  Such a loader has kPreSplit = true and planes(raw, p, hi, mid, lo) instead of finish().

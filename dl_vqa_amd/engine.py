@@ -79,6 +79,12 @@ class Engine:
         """fp32x3 mode: does this conv block (NHWC input shape, output channels) run on the split kernels?"""
         return self.x3 and len(x_shape) == 4 and ops.conv_x3_supported(x_shape[1], x_shape[2], x_shape[3], Co, self.stride)
 
+    def _out_shape(self, x, l, fast0):
+        """NHWC shape of block l's pooled output for input activation x (the NCHW image for the dedicated first block)."""
+        B, H, W = (x.shape[0], x.shape[2], x.shape[3]) if (l == 0 and fast0) else ops.nhwc_shape(x)[:3]
+        Hp, Wp = ops.conv_out_hw(H, W, self.stride)
+        return (B, Hp, Wp, self.channels[l + 1])
+
     def _side_streams(self, dev):
         # VQA_STREAMS: 0 = one stream; 1 = the question branch on a side stream, joined before the image branch;
         # 2 (default) = the question branch runs UNDER the convolutions (forward: joined before the attention stage,
@@ -207,9 +213,13 @@ class Engine:
         for l in range(self.L):
             w = P[f"image.conv{l}.weight"]
             assert w.shape[0] == self.channels[l + 1]
+            # fp32x3: a block whose successor runs on the split kernels writes its output x3-packed (split once per
+            # tensor by the producer's epilogue; forward and wgrad of the successor read that form)
+            nxt_x3 = l + 1 < self.L and self._x3_layer(self._out_shape(acts[-1], l, fast0), self.channels[l + 2])
             if l == 0 and fast0:
                 pooled, am = ops.conv0_fwd(v, w, P["image.conv0.bias"],
-                                           out_dtype=torch.bfloat16 if self.bf16 else torch.float32, bf16_mfma=self.bf16)
+                                           out_dtype=torch.bfloat16 if self.bf16 else torch.float32, bf16_mfma=self.bf16,
+                                           out_packed=nxt_x3)
                 acts.append(pooled)
                 idxs.append(am)
                 wds.append(None)
@@ -226,11 +236,17 @@ class Engine:
                 idxs.append(am)
                 wds.append(wdT)
                 continue
-            wf, wd = ops.conv_pack_weights(w, acts[-1].shape[3], need_wd=(keep and l > 0))
-            x3 = self._x3_layer(acts[-1].shape, w.shape[0])
-            if x3:      # the weights are split once per step, not by every workgroup in every K-step
+            x_shape = ops.nhwc_shape(acts[-1])
+            wf, wd = ops.conv_pack_weights(w, x_shape[3], need_wd=(keep and l > 0))
+            x3 = self._x3_layer(x_shape, w.shape[0])
+            if x3:
+                # operands are split once per tensor, not by every workgroup in every K-step: the weights here, the
+                # input activation by its producer (or here, when the producer could not: it replaces the fp32 tensor)
                 wf, wd = ops.x3_split(wf), (ops.x3_split(wd) if wd is not None else None)
-            pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l, x3=x3)
+                if acts[-1].dim() == 4:
+                    acts[-1] = ops.x3_pack(acts[-1])
+            pooled, am = ops.conv_fwd(acts[-1], wf, P[f"image.conv{l}.bias"], self.stride, tag=l, x3=x3,
+                                      out_packed=x3 and nxt_x3)
             acts.append(pooled)
             idxs.append(am)
             wds.append(wd)
@@ -477,10 +493,11 @@ class Engine:
                                     self.stride, tag=l)
                 dP = ops.conv_dgrad_bf16(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride, tag=l)
                 continue
-            x3 = self._x3_layer(ctx.acts[l].shape, dP.shape[3])
+            x_shape = ops.nhwc_shape(ctx.acts[l])
+            x3 = self._x3_layer(x_shape, dP.shape[3])
             ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
                            self.stride, tag=l, x3=x3)
             if l > 0:
-                dP = ops.conv_dgrad(dP, ctx.idxs[l], ctx.wds[l], ctx.acts[l].shape, self.stride, tag=l, x3=x3)
+                dP = ops.conv_dgrad(dP, ctx.idxs[l], ctx.wds[l], x_shape, self.stride, tag=l, x3=x3)
         ready("image")
         main.wait_event(ev0)

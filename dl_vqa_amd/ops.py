@@ -74,21 +74,52 @@ def x3_split(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def x3_pack(x: torch.Tensor) -> torch.Tensor:
+    """fp32 activation [..., C] (C % 4 == 0) -> the x3-packed form [..., C/4, 3, 4] bf16: every four channels as
+    hi[4] mid[4] lo[4] (include/vqa_hip.h vqa_x3_pack); accepted as the input of conv_fwd / conv_wgrad with x3=True."""
+    assert x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.is_contiguous()
+    out = torch.empty(tuple(x.shape[:-1]) + (x.shape[-1] // 4, 3, 4), dtype=torch.bfloat16, device=x.device)
+    call("vqa_x3_pack", ptr(x), ptr(out), x.numel(), stream())
+    return out
+
+
+def nhwc_shape(x) -> tuple:
+    """(B, H, W, C) of an NHWC activation, fp32 / bf16 [B,H,W,C] or x3-packed [B,H,W,C/4,3,4]."""
+    if x.dim() == 6:
+        return (x.shape[0], x.shape[1], x.shape[2], x.shape[3] * 4)
+    return tuple(x.shape)
+
+
+def _x3_input(x):
+    """(B, H, W, CiP, packed) of a conv input that is fp32 NHWC or x3-packed."""
+    if x.dtype == torch.bfloat16 and x.dim() == 6:
+        return x.shape[0], x.shape[1], x.shape[2], x.shape[3] * 4, 1
+    assert x.dtype == torch.float32 and x.dim() == 4
+    return x.shape[0], x.shape[1], x.shape[2], x.shape[3], 0
+
+
 def conv_x3_supported(H: int, W: int, CiP: int, Co: int, stride: int) -> bool:
     return bool(_lib.load().vqa_conv3x3_x3_supported(H, W, CiP, Co, stride))
 
 
-def conv_fwd(x: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False):
+def conv_fwd(x: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False,
+             out_packed: bool = False):
     """x NHWC [B,H,W,CiP] -> (pooled [B,Hp,Wp,Co], argmax uint8 same shape).  x3: fp32 on the bf16 matrix cores
     (exact 3 x bf16 operand split, csrc/x3_core.hpp) instead of the fp32 MFMA; wf is then x3_split(packed weights)."""
-    B, H, W, CiP = x.shape
+    B, H, W, CiP, packed = _x3_input(x) if x3 else (*x.shape, 0)
     Co = wf.shape[-1]
     assert (wf.dtype == torch.bfloat16 and wf.dim() == 3) if x3 else wf.dtype == torch.float32
     Hp, Wp = conv_out_hw(H, W, stride)
-    pooled = torch.empty(B, Hp, Wp, Co, dtype=torch.float32, device=x.device)
+    assert x3 or not out_packed
+    pooled = (torch.empty(B, Hp, Wp, Co // 4, 3, 4, dtype=torch.bfloat16, device=x.device) if out_packed else
+              torch.empty(B, Hp, Wp, Co, dtype=torch.float32, device=x.device))
     amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x.device)
-    call("vqa_conv3x3_relu_pool_fwd_x3" if x3 else "vqa_conv3x3_relu_pool_fwd", ptr(x), ptr(wf), ptr(bias), ptr(pooled),
-         ptr(amax), B, H, W, CiP, Co, stride, tag, stream())
+    if x3:
+        call("vqa_conv3x3_relu_pool_fwd_x3", ptr(x), packed, ptr(wf), ptr(bias), ptr(pooled), int(out_packed), ptr(amax),
+             B, H, W, CiP, Co, stride, tag, stream())
+    else:
+        call("vqa_conv3x3_relu_pool_fwd", ptr(x), ptr(wf), ptr(bias), ptr(pooled), ptr(amax), B, H, W, CiP, Co, stride,
+             tag, stream())
     return pooled, amax
 
 
@@ -104,11 +135,15 @@ def conv_dgrad(dpooled, amax, wd, x_shape, stride: int = 1, tag: int = 0, out=No
 
 def conv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False):
     lib = _lib.load()
-    B, H, W, CiP = x.shape
+    B, H, W, CiP, packed = _x3_input(x) if x3 else (*x.shape, 0)
     Co, Ci = dw.shape[0], dw.shape[1]
     nbytes = (lib.vqa_conv3x3_wgrad_x3_workspace_bytes if x3 else lib.vqa_conv3x3_wgrad_workspace_bytes)(B, H, W, CiP, Co, stride)
     ws = workspace(nbytes, x.device)
-    call("vqa_conv3x3_wgrad_x3" if x3 else "vqa_conv3x3_wgrad", ptr(x), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co, stride,
+    if x3:
+        call("vqa_conv3x3_wgrad_x3", ptr(x), packed, ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co,
+             stride, ptr(ws), ws.numel() * 4, tag, stream())
+        return
+    call("vqa_conv3x3_wgrad", ptr(x), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co, stride,
          ptr(ws), ws.numel() * 4, tag, stream())
 
 
@@ -116,15 +151,18 @@ def conv0_supported(Ci: int, H: int, W: int, Co: int, stride: int) -> bool:
     return bool(_lib.load().vqa_conv0_supported(Ci, H, W, Co, stride))
 
 
-def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype=torch.float32, bf16_mfma=False):
+def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype=torch.float32, bf16_mfma=False,
+              out_packed=False):
     """First conv block straight from the NCHW image: (pooled NHWC [B,Hp,Wp,Co] fp32 or bf16, argmax uint8).
-    bf16_mfma (bf16 output only): image and weights rounded to bf16, bf16 MFMA."""
+    bf16_mfma (bf16 output only): image and weights rounded to bf16, bf16 MFMA.  out_packed: fp32 MFMA, the output
+    written in the x3-packed form [B,Hp,Wp,Co/4,3,4] bf16 (see x3_pack)."""
     B, Ci, H, W = x_nchw.shape
     Co = w.shape[0]
     Hp, Wp = conv_out_hw(H, W, 1)
-    pooled = torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x_nchw.device)
+    pooled = (torch.empty(B, Hp, Wp, Co // 4, 3, 4, dtype=torch.bfloat16, device=x_nchw.device) if out_packed else
+              torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x_nchw.device))
     amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x_nchw.device)
-    mode = (2 if bf16_mfma else 1) if out_dtype == torch.bfloat16 else 0
+    mode = 3 if out_packed else (2 if bf16_mfma else 1) if out_dtype == torch.bfloat16 else 0
     call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(pooled), mode, ptr(amax), B, Ci, H, W, Co, stream())
     return pooled, amax
 

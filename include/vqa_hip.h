@@ -118,7 +118,8 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
 int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride);
 int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, void* pooled,
                             int pooled_is_bf16 /* 0: fp32 out; 1: fp32 MFMA, P_0 stored as bf16; 2 (bf16 path):
-                            image and weights rounded to bf16, two 32x32x16 bf16 MFMA k-steps, bf16 out */, uint8_t* argmax, int B, int Ci,
+                            image and weights rounded to bf16, two 32x32x16 bf16 MFMA k-steps, bf16 out; 3 (fp32x3 path): fp32
+                            MFMA, the output written x3-packed (vqa_x3_pack's form, 6 bytes per element) */, uint8_t* argmax, int B, int Ci,
                             int H, int W, int Co, vqa_stream_t stream);
 int64_t vqa_conv0_wgrad_workspace_bytes(int Co);
 int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias,
@@ -314,14 +315,20 @@ int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* ar
 int vqa_conv3x3_x3_supported(int H, int W, int CiP, int Co, int stride);
 /* the operand split of those kernels on its own (tests): x[n] -> three planes of n bf16, x == hi + mid + lo exactly */
 int vqa_x3_split(const float* x, void* hi, void* mid, void* lo, int64_t n /* multiple of 4 */, vqa_stream_t stream);
-int vqa_conv3x3_relu_pool_fwd_x3(const float* x, const void* wf_planes, const float* bias, float* pooled, uint8_t* argmax,
-                                 int B, int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream);
+/* x3-packed activations: a tensor [pixels][C] (C % 4 == 0) split once per tensor instead of by every workgroup that
+ * reads it: every four consecutive channels are 24 bytes hi[4] mid[4] lo[4] bf16 (6 bytes per element, same order).
+ * The forward and wgrad entry points take their input x either as fp32 (x_packed = 0) or in this form (1). */
+int vqa_x3_pack(const float* x, void* out /* 6 bytes per element */, int64_t n /* multiple of 4 */, vqa_stream_t stream);
+int vqa_conv3x3_relu_pool_fwd_x3(const void* x, int x_packed, const void* wf_planes, const float* bias, void* pooled,
+                                 int pooled_packed /* 1: the output is written x3-packed, for the next block */,
+                                 uint8_t* argmax, int B, int H, int W, int CiP, int Co, int stride, int tag,
+                                 vqa_stream_t stream);
 int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const void* wd_planes, float* dx, int B, int H, int W,
                          int CiP, int Co, int stride, int tag, vqa_stream_t stream);
 int64_t vqa_conv3x3_wgrad_x3_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride);
-int vqa_conv3x3_wgrad_x3(const float* x, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B,
-                         int H, int W, int CiP, int Ci, int Co, int stride, float* workspace, int64_t workspace_bytes,
-                         int tag, vqa_stream_t stream);
+int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, const uint8_t* argmax, float* dw,
+                         float* dbias, int B, int H, int W, int CiP, int Ci, int Co, int stride, float* workspace,
+                         int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
 /* ---- optimiser: torch.optim.Adam defaults over one flat buffer (train.py:55,80) ------------- */
 int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -135,6 +135,140 @@ struct WgradAx {   // A(i = (ky,kx,ci), m) = x[b][yo*s+ky][xo*s+kx][ci], x3-pack
   }
 };
 
+// ------------------------------------------------------------------ routed operands from an x3-packed pooled gradient
+// dgrad's A and wgrad's B rebuild dY from the pooled gradient and the arg-max bytes (conv_device.inc route4).  On the
+// packed form the routing is a mask on 16-bit halves, shared by the three planes: 8 VALU for the masks of four elements
+// + 6 ANDs, against 8 (route4) + 14 (split4) on an fp32 gradient.
+// id = the four arg-max bytes of the chunk, jrep = the pixel's position in its window in every byte.
+__device__ __forceinline__ void route_masks(uint32_t id, uint32_t jrep, uint32_t& m01, uint32_t& m23) {
+  const uint32_t t = id ^ jrep;                               // bytes 0..7; zero where this pixel is the arg-max
+  const uint32_t g = (0x08080808u - t) & 0x08080808u;         // 0x08 per matching byte (no borrows: every byte of t < 8)
+  const uint32_t b = (g << 5) - (g >> 3);                     // 0xff per matching byte
+  m01 = __builtin_amdgcn_perm(b, b, 0x01010000u);             // bytes (b1 b1 b0 b0): element 0 is the low half
+  m23 = __builtin_amdgcn_perm(b, b, 0x03030202u);
+}
+__device__ __forceinline__ void route_planes(const float4 a, const uint2 bb, uint32_t id, uint32_t jrep, uint2& hi,
+                                             uint2& mid, uint2& lo) {
+  uint32_t m01, m23;
+  route_masks(id, jrep, m01, m23);
+  hi = make_uint2(__float_as_uint(a.x) & m01, __float_as_uint(a.y) & m23);
+  mid = make_uint2(__float_as_uint(a.z) & m01, __float_as_uint(a.w) & m23);
+  lo = make_uint2(bb.x & m01, bb.y & m23);
+}
+
+// ConvDgradA<UT> over an x3-packed pooled gradient (byte offsets x 6 / 4; the arg-max offsets stay in elements)
+template <int NV, int LT>
+struct ConvDgradAx {
+  struct Params { const void* dp; const uint8_t* am; int H, W, Hp, Wp, Co, stride, rows, K; };
+  struct Raw { float4 a[NV]; uint2 b[NV]; uint32_t id[NV]; uint32_t j[NV]; };
+  static constexpr bool kTypeR = true;
+  static constexpr bool kPreSplit = true;
+  Params q;
+  int b[NV], y[NV], x[NV];
+  uint32_t vd[NV], va[NV];
+  uint32_t jc[NV];             // the row's position in its source window for the current tap, in every byte
+  int curtap, c4;
+  TapCursor cur;
+  __device__ __forceinline__ void init(const Params& q_, int row0, int tid, int ks0) {
+    q = q_;
+    c4 = 4 * StageMap<LT>::r_chunk(tid);
+    cur.init(ks0 * BK, q.Co);
+    curtap = -1;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int m = row0 + StageMap<LT>::r_row(tid, p);
+      const int mm = m < q.rows ? m : 0;
+      x[p] = m < q.rows ? mm % q.W : -1;
+      const int t = mm / q.W;
+      y[p] = t % q.H;
+      b[p] = t / q.H;
+      vd[p] = va[p] = BUF_OOB;
+      jc[p] = 0;
+    }
+  }
+  __device__ __forceinline__ void retap(int tap, int c) {
+    const bool kok = tap < 9;
+    const int tp = kok ? tap : 0;
+    const int ky = tp / 3, kx = tp - 3 * ky;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      int yy = y[p] - ky, xx = x[p] - kx;
+      bool v = kok && yy >= 0 && xx >= 0;
+      if (q.stride == 2) { v = v && !(yy & 1) && !(xx & 1); yy >>= 1; xx >>= 1; }
+      v = v && yy < 2 * q.Hp && xx < 2 * q.Wp;
+      const uint32_t e = (uint32_t)((b[p] * q.Hp + (yy >> 1)) * q.Wp + (xx >> 1)) * (uint32_t)q.Co + (uint32_t)c;
+      vd[p] = v ? e * 6u : BUF_OOB;
+      va[p] = v ? e : BUF_OOB;
+      jc[p] = (uint32_t)(((yy & 1) << 1) | (xx & 1)) * 0x01010101u;
+    }
+  }
+  __device__ __forceinline__ void issue(int /*ks*/, Raw& r) {
+    if (cur.tap != curtap) { retap(cur.tap, c4); curtap = cur.tap; }
+    const __amdgpu_buffer_rsrc_t rd = buf_rsrc(static_cast<const char*>(q.dp) + (int64_t)cur.ch * 6), ra = buf_rsrc(q.am + cur.ch);
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      r.a[p] = buf_load16(rd, vd[p]);
+      r.b[p] = buf_load8(rd, vd[p], 16);
+      r.id[p] = AM_LOAD(ra, va[p]);
+      r.j[p] = jc[p];
+    }
+    cur.advance();
+  }
+  __device__ __forceinline__ void planes(const Raw& r, int p, uint2& hi, uint2& mid, uint2& lo) const {
+    route_planes(r.a[p], r.b[p], r.id[p], r.j[p], hi, mid, lo);
+  }
+};
+
+// WgradB<uniform> over an x3-packed pooled gradient
+template <int NV, int LT>
+struct WgradBx {
+  struct Params { const void* dp; const uint8_t* am; WgradGeom g; };
+  struct Raw { float4 a[NV]; uint2 b[NV]; uint32_t id[NV]; uint32_t j; };
+  static constexpr bool kTypeR = false;
+  static constexpr bool kPreSplit = true;
+  Params q;
+  uint32_t le0, leE;        // lane constants in ELEMENTS: (kr >> 1) * Co + 4 * (lane & 7); leE = le0 - Wp * Co
+  uint32_t j0;
+  int kr, n0, hw;
+  RowCursor rc;
+  __device__ __forceinline__ void init(const Params& q_, int n0_, int tid, int ks0) {
+    q = q_; n0 = n0_;
+    kr = StageMap<LT>::c_krow(tid);
+    hw = __builtin_amdgcn_readfirstlane(tid >> 8);
+    rc.init(ks0 * BK, q.g.Hp, q.g.Wp);
+    le0 = (uint32_t)(kr >> 1) * (uint32_t)q.g.Co + 4u * (uint32_t)(tid & 7);
+    leE = le0 - (uint32_t)q.g.Wp * (uint32_t)q.g.Co;
+    j0 = (uint32_t)(kr & 1);
+  }
+  __device__ __forceinline__ void issue(int ks, Raw& r) {
+    // the packed gradient is < 4 GiB, so its element offsets stay below BUF_OOB / 6: the arg-max resource ends there
+    const __amdgpu_buffer_rsrc_t rd = buf_rsrc(static_cast<const char*>(q.dp) + (int64_t)n0 * 6),
+                                 ra = buf_rsrc(q.am + n0, BUF_OOB / 6u);
+    const int n1 = rc.Wo2 - rc.xs;
+    const bool odd = rc.yo & 1;
+    const int R = rc.b * rc.Ho2 + rc.yo;
+    const uint32_t base = (uint32_t)((R >> 1) * q.g.Wp + (rc.xs >> 1)) * (uint32_t)q.g.Co;
+    const bool second = kr >= n1;
+    uint32_t el = (second && !odd ? leE : le0) + base;
+    r.j = (j0 + (second != odd ? 2u : 0u)) * 0x01010101u;
+    const bool dead = (ks + 1) * BK > q.g.Mtot && !(rc.m0 + kr < q.g.Mtot);   // last K-step / past the end
+    const uint32_t off = dead ? BUF_OOB : el * 6u;
+    const uint32_t offa = dead ? BUF_OOB : el;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+      const int grp = hw + (LT / 256) * p;
+      const uint32_t pp = n0 + BK * grp < q.g.Co ? grp : 0;
+      r.a[p] = buf_load16(rd, off, 192u * pp);
+      r.b[p] = buf_load8(rd, off, 192u * pp + 16u);
+      r.id[p] = AM_LOAD(ra, offa, 32u * pp);
+    }
+    rc.advance();
+  }
+  __device__ __forceinline__ void planes(const Raw& r, int p, uint2& hi, uint2& mid, uint2& lo) const {
+    route_planes(r.a[p], r.b[p], r.id[p], r.j, hi, mid, lo);
+  }
+};
+
 // conv_pool_epilogue with the pooled activation written in the x3-packed form (the next block's input): bit-identical
 // to vqa_x3_pack of the fp32 output.
 template <class Cfg>
@@ -205,8 +339,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename A
   else conv_pool_epilogue<Cfg>(acc, bias, pooled, amax, pa.nWin, Co, m0, n0, wm, wn, lane);
 }
 
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename ConvDgradA<Cfg::NVA, Cfg::LT, true>::Params pa,
+template <class Cfg, class AL>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename AL::Params pa,
                                                                         typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
                                                                         float* dx, int CiP, int tiles_m, int tiles_n, int nk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -214,7 +348,6 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const TileCoord tc = tile_coord(tiles_m, tiles_n);
   const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
-  using AL = ConvDgradA<Cfg::NVA, Cfg::LT, true>;
   using BL = PlainCx<Cfg::NVB, Cfg::LT>;
   f32x16 acc[Cfg::TM][Cfg::TN];
   acc_zero<Cfg>(acc);
@@ -228,9 +361,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename
   store_acc_tiles<Cfg>(acc, dx, CiP, pa.rows, CiP, m0, n0, wm, wn, lane);
 }
 
-template <class Cfg, class AL>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename AL::Params pa,
-                                                                        typename WgradB<Cfg::NVB, Cfg::LT, true>::Params pb,
+template <class Cfg, class AL, class BL>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename AL::Params pa, typename BL::Params pb,
                                                                         float* slab, int tiles_m, int tiles_n, int nk,
                                                                         int ks_per_split) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -240,7 +372,6 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename
   const int m0 = tc.mt * Cfg::BM, n0 = tc.nt * Cfg::BN;
   const int ks0 = tc.split * ks_per_split;
   const int ks1 = min(nk, ks0 + ks_per_split);
-  using BL = WgradB<Cfg::NVB, Cfg::LT, true>;
   f32x16 acc[Cfg::TM][Cfg::TN];
   acc_zero<Cfg>(acc);
   if (!gemm_mainloop_x<Cfg, AL, BL>(
@@ -269,15 +400,15 @@ static int launch_fwd_x3(const void* x, const void* wf, const float* bias, void*
   return check_hip(hipGetLastError(), "conv_fwd_x3 launch");
 }
 
-template <class Cfg>
-static int launch_dgrad_x3(const float* dp, const uint8_t* am, const void* wd, float* dx, const ConvGeom& g,
+template <class Cfg, class AL>
+static int launch_dgrad_x3(const void* dp, const uint8_t* am, const void* wd, float* dx, const ConvGeom& g,
                            hipStream_t s) {
   using SL = SmemLayoutX<Cfg, true, false>;
   const int rows = g.B * g.H * g.W, K = 9 * g.Co;
-  typename ConvDgradA<Cfg::NVA, Cfg::LT, true>::Params pa{dp, am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
+  typename AL::Params pa{static_cast<decltype(AL::Params::dp)>(dp), am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
   typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb{wd, g.CiP, g.CiP, K, (int64_t)K * g.CiP};
   const int tiles_m = (rows + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.CiP + Cfg::BN - 1) / Cfg::BN;
-  auto kern = conv_dgrad_x3_kernel<Cfg>;
+  auto kern = conv_dgrad_x3_kernel<Cfg, AL>;
   { int rc = set_smem(kern, SL::BYTES, "attr(conv_dgrad_x3)"); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, dx, g.CiP, tiles_m,
                      tiles_n, K / BK);
@@ -301,6 +432,39 @@ static WgradPlanX plan_wgrad_x3(const ConvGeom& g) {
   return p;
 }
 
+// bias gradient = sum over the windows that are not dead (arg-max != 4) of the fp32 pooled gradient; deterministic.  A
+// thread owns 4 consecutive channels (one 16-byte load of dP + 4 arg-max bytes per window), the Co/4 threads of a
+// window sit side by side, 256 / (Co/4) window lanes per block combine through LDS in a fixed order; the blocks write
+// part rows that wgrad_bias_reduce_kernel adds up.  Co % 4 == 0, Co <= 1024.  (The split kernels' B fragments are bf16
+// planes: summing them in the MFMA waves as conv.hip does would cost more than this pass over 0.1-0.4 GB.)
+constexpr int kBiasParts = 1024;
+__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const float* dp, const uint8_t* am, float* part,
+                                                             int64_t windows, int Co, int64_t per) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [window lanes][Co]
+  const int cpr = Co / 4, nwl = 256 / cpr;
+  const int c = threadIdx.x % cpr, wl = threadIdx.x / cpr;
+  const int64_t w0 = (int64_t)blockIdx.x * per;
+  const int64_t w1 = w0 + per < windows ? w0 + per : windows;
+  float4 acc = f4zero();
+  if (wl < nwl) {
+    for (int64_t w = w0 + wl; w < w1; w += nwl) {
+      const float4 d = *reinterpret_cast<const float4*>(dp + w * Co + 4 * c);
+      const uint32_t a = *reinterpret_cast<const uint32_t*>(am + w * Co + 4 * c);
+      acc.x += (a & 0xffu) != 4u ? d.x : 0.f;
+      acc.y += ((a >> 8) & 0xffu) != 4u ? d.y : 0.f;
+      acc.z += ((a >> 16) & 0xffu) != 4u ? d.z : 0.f;
+      acc.w += (a >> 24) != 4u ? d.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(red + wl * Co + 4 * c) = acc;
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < Co; co += 256) {
+    float v = 0.f;
+    for (int l = 0; l < nwl; ++l) v += red[l * Co + co];
+    part[(int64_t)blockIdx.x * Co + co] = v;
+  }
+}
+
 // the operand split on its own (tests): planes of n bf16 each
 __global__ void x3_split_kernel(const float4* x, uint2* hi, uint2* mid, uint2* lo, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,9 +481,11 @@ __global__ void x3_pack_kernel(const float4* x, uint2* out, int64_t n4) {
 }
 
 static bool x3_conv_ok(int CiP, int Co, int Wp) { return CiP % BK == 0 && Co % BK == 0 && 2 * Wp >= BK; }
-// images per launch: as batch_chunk, with the input tensor at 6 bytes per element (the packed form; also used for
-// fp32 inputs so that the forward / wgrad / workspace computations agree whatever the input form)
-static int x3_chunk(int B, int H, int W, int CiP, int Co, int stride) { return batch_chunk(B, H, W, CiP / 2 * 3, Co, stride); }
+// images per launch: as batch_chunk, with the tensors at 6 bytes per element (the packed forms; also used for fp32
+// tensors so that the forward / dgrad / wgrad / workspace computations agree whatever the form)
+static int x3_chunk(int B, int H, int W, int CiP, int Co, int stride) {
+  return batch_chunk(B, H, W, CiP / 2 * 3, Co / 2 * 3, stride);
+}
 
 }  // namespace vqa
 
@@ -385,11 +551,11 @@ int vqa_conv3x3_relu_pool_fwd_x3(const void* x, int x_packed, const void* wf, co
   return VQA_OK;
 }
 
-int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const void* wd, float* dx, int B, int H, int W,
-                         int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
+int vqa_conv3x3_dgrad_x3(const void* dpooled, int dp_packed, const uint8_t* argmax, const void* wd, float* dx, int B,
+                         int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream) {
   VQA_REQUIRE(dpooled && argmax && wd && dx && B > 0, "vqa_conv3x3_dgrad_x3: null pointer");
   VQA_REQUIRE(Co % BK == 0, "vqa_conv3x3_dgrad_x3: Co=%d must be a multiple of %d", Co, BK);
-  const int chunk = batch_chunk(B, H, W, CiP, Co, stride);
+  const int chunk = x3_chunk(B, H, W, CiP, Co, stride);
   VQA_REQUIRE(chunk > 0, "vqa_conv3x3_dgrad_x3: one %dx%dx%d image reaches 4 GiB", H, W, CiP);
   const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
   set_launch_tag(tag);
@@ -400,8 +566,14 @@ int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const void
     const ConvGeom g = make_geom(nb, H, W, CiP, Co, stride);
     int rc = check_geom("vqa_conv3x3_dgrad_x3", g);
     if (rc) return rc;
-    rc = CiP > 64 ? launch_dgrad_x3<CfgX>(dpooled + po, argmax + po, wd, dx + xo, g, (hipStream_t)stream)
-                  : launch_dgrad_x3<CfgXn>(dpooled + po, argmax + po, wd, dx + xo, g, (hipStream_t)stream);
+    const void* dpc = static_cast<const char*>(dpooled) + po * (dp_packed ? 6 : 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dp_packed)
+      rc = CiP > 64 ? launch_dgrad_x3<CfgX, ConvDgradAx<CfgX::NVA, CfgX::LT>>(dpc, argmax + po, wd, dx + xo, g, st)
+                    : launch_dgrad_x3<CfgXn, ConvDgradAx<CfgXn::NVA, CfgXn::LT>>(dpc, argmax + po, wd, dx + xo, g, st);
+    else
+      rc = CiP > 64 ? launch_dgrad_x3<CfgX, ConvDgradA<CfgX::NVA, CfgX::LT, true>>(dpc, argmax + po, wd, dx + xo, g, st)
+                    : launch_dgrad_x3<CfgXn, ConvDgradA<CfgXn::NVA, CfgXn::LT, true>>(dpc, argmax + po, wd, dx + xo, g, st);
     if (rc) return rc;
   }
   return VQA_OK;
@@ -415,14 +587,14 @@ int64_t vqa_conv3x3_wgrad_x3_workspace_bytes(int B, int H, int W, int CiP, int C
   int64_t parts = 0;
   for (int b0 = 0; b0 < B; b0 += chunk)
     parts += plan_wgrad_x3(make_geom(B - b0 < chunk ? B - b0 : chunk, H, W, CiP, Co, stride)).splits;
-  return parts * (int64_t)9 * CiP * Co * 4 + colsum_ws_bytes((int64_t)B * g1.Hp * g1.Wp, Co);
+  return parts * (int64_t)9 * CiP * Co * 4 + (int64_t)kBiasParts * Co * 4;
 }
 
-int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, const uint8_t* argmax, float* dw,
-                         float* dbias, int B, int H, int W, int CiP, int Ci, int Co, int stride, float* workspace,
-                         int64_t workspace_bytes, int tag, vqa_stream_t stream) {
+int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, const void* dpooled_packed,
+                         const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W, int CiP, int Ci, int Co,
+                         int stride, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream) {
   VQA_REQUIRE(x && dpooled && argmax && dw && dbias && workspace && B > 0, "vqa_conv3x3_wgrad_x3: null pointer");
-  VQA_REQUIRE(Ci >= 1 && Ci <= CiP, "vqa_conv3x3_wgrad_x3: Ci=%d CiP=%d", Ci, CiP);
+  VQA_REQUIRE(Ci >= 1 && Ci <= CiP && Co <= 1024, "vqa_conv3x3_wgrad_x3: Ci=%d CiP=%d Co=%d (Co <= 1024)", Ci, CiP, Co);
   const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
   VQA_REQUIRE(g1.Hp > 0 && g1.Wp > 0 && x3_conv_ok(CiP, Co, g1.Wp),
               "vqa_conv3x3_wgrad_x3: needs CiP, Co multiples of %d and 2*Wp >= %d (CiP=%d Co=%d Wp=%d)", BK, BK, CiP, Co, g1.Wp);
@@ -451,27 +623,31 @@ int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, cons
     using SL = SmemLayoutX<CfgX, false, false>;
     WgradGeom wg{g.H, g.W, g.CiP, g.Hp, g.Wp, g.Co, g.stride, p.Mtot};
     const int64_t po = (int64_t)b0 * g1.Hp * g1.Wp * Co;
-    typename WgradB<CfgX::NVB, CfgX::LT, true>::Params pb{dpooled + po, argmax + po, wg};
     const char* xc = static_cast<const char*>(x) + (int64_t)b0 * H * W * CiP * (x_packed ? 6 : 4);
     const dim3 grid(p.tiles_m * p.tiles_n * p.splits);
     float* slab = workspace + (int64_t)done * KI * Co;
-    if (x_packed) {
-      using AL = WgradAx<CfgX::NVA, CfgX::LT>;
-      typename AL::Params pa{xc, wg, p.KI};
-      auto kern = conv_wgrad_x3_kernel<CfgX, AL>;
-      rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad_x3p)");
-      if (rc) return rc;
-      hipLaunchKernelGGL(kern, grid, dim3(CfgX::THREADS), SL::BYTES, s, pa, pb, slab, p.tiles_m, p.tiles_n, p.nk,
-                         p.ks_per_split);
-    } else {
-      using AL = WgradA<CfgX::NVA, CfgX::LT, true>;
-      typename AL::Params pa{reinterpret_cast<const float*>(xc), wg, p.KI};
-      auto kern = conv_wgrad_x3_kernel<CfgX, AL>;
-      rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad_x3)");
-      if (rc) return rc;
-      hipLaunchKernelGGL(kern, grid, dim3(CfgX::THREADS), SL::BYTES, s, pa, pb, slab, p.tiles_m, p.tiles_n, p.nk,
-                         p.ks_per_split);
+    using AF = WgradA<CfgX::NVA, CfgX::LT, true>;
+    using AP = WgradAx<CfgX::NVA, CfgX::LT>;
+    using BF = WgradB<CfgX::NVB, CfgX::LT, true>;
+    using BP = WgradBx<CfgX::NVB, CfgX::LT>;
+#define X3_WGRAD(AL, BL, XPTR, DPTR)                                                                                   \
+    {                                                                                                                  \
+      typename AL::Params pa{XPTR, wg, p.KI};                                                                          \
+      typename BL::Params pb{DPTR, argmax + po, wg};                                                                   \
+      auto kern = conv_wgrad_x3_kernel<CfgX, AL, BL>;                                                                  \
+      rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad_x3)");                                                           \
+      if (rc) return rc;                                                                                               \
+      hipLaunchKernelGGL(kern, grid, dim3(CfgX::THREADS), SL::BYTES, s, pa, pb, slab, p.tiles_m, p.tiles_n, p.nk,      \
+                         p.ks_per_split);                                                                              \
     }
+    const float* xf = reinterpret_cast<const float*>(xc);
+    const float* dpf = dpooled + po;
+    const void* dpp = dpooled_packed ? static_cast<const char*>(dpooled_packed) + po * 6 : nullptr;
+    if (x_packed && dpp) X3_WGRAD(AP, BP, xc, dpp)
+    else if (x_packed) X3_WGRAD(AP, BF, xc, dpf)
+    else if (dpp) X3_WGRAD(AF, BP, xf, dpp)
+    else X3_WGRAD(AF, BF, xf, dpf)
+#undef X3_WGRAD
     rc = check_hip(hipGetLastError(), "conv_wgrad_x3 launch");
     if (rc) return rc;
     done += p.splits;
@@ -482,7 +658,14 @@ int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, cons
   if (rc) return rc;
   // bias gradient = sum of the pooled gradient over the windows whose ReLU was alive (arg-max byte != 4)
   const int64_t rows = (int64_t)B * g1.Hp * g1.Wp;
-  return colsum_launch(dpooled, Co, argmax, rows, Co, dbias, 0, colsum_ws, colsum_ws_bytes(rows, Co), s);
+  const int nparts = rows < kBiasParts ? (int)rows : kBiasParts;
+  const int64_t per = (rows + nparts - 1) / nparts;
+  hipLaunchKernelGGL(conv_bias_grad_kernel, dim3(nparts), dim3(256), (size_t)(256 / (Co / 4)) * Co * 4, s, dpooled, argmax,
+                     colsum_ws, rows, Co, per);
+  rc = check_hip(hipGetLastError(), "conv_bias_grad launch");
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, colsum_ws, dbias, nparts, Co);
+  return check_hip(hipGetLastError(), "wgrad_bias_reduce launch");
 }
 
 }  // extern "C"

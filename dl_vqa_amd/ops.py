@@ -124,24 +124,30 @@ def conv_fwd(x: torch.Tensor, wf: torch.Tensor, bias: torch.Tensor, stride: int 
 
 
 def conv_dgrad(dpooled, amax, wd, x_shape, stride: int = 1, tag: int = 0, out=None, x3: bool = False) -> torch.Tensor:
+    """dpooled: fp32 [B,Hp,Wp,Co], or (x3 only) its x3-packed form (x3_pack)."""
     B, H, W, CiP = x_shape
-    Co = dpooled.shape[3]
+    Co = nhwc_shape(dpooled)[3]
     assert (wd.dtype == torch.bfloat16 and wd.dim() == 3) if x3 else wd.dtype == torch.float32
     dx = out if out is not None else torch.empty(B, H, W, CiP, dtype=torch.float32, device=dpooled.device)
-    call("vqa_conv3x3_dgrad_x3" if x3 else "vqa_conv3x3_dgrad", ptr(dpooled), ptr(amax), ptr(wd), ptr(dx), B, H, W, CiP,
-         Co, stride, tag, stream())
+    if x3:
+        call("vqa_conv3x3_dgrad_x3", ptr(dpooled), int(dpooled.dim() == 6), ptr(amax), ptr(wd), ptr(dx), B, H, W, CiP, Co,
+             stride, tag, stream())
+    else:
+        call("vqa_conv3x3_dgrad", ptr(dpooled), ptr(amax), ptr(wd), ptr(dx), B, H, W, CiP, Co, stride, tag, stream())
     return dx
 
 
-def conv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False):
+def conv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False,
+               dpooled_packed=None):
+    """x3: x may be x3-packed; dpooled_packed (optional) = x3_pack(dpooled), read by the contraction instead of dpooled."""
     lib = _lib.load()
     B, H, W, CiP, packed = _x3_input(x) if x3 else (*x.shape, 0)
     Co, Ci = dw.shape[0], dw.shape[1]
     nbytes = (lib.vqa_conv3x3_wgrad_x3_workspace_bytes if x3 else lib.vqa_conv3x3_wgrad_workspace_bytes)(B, H, W, CiP, Co, stride)
     ws = workspace(nbytes, x.device)
     if x3:
-        call("vqa_conv3x3_wgrad_x3", ptr(x), packed, ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co,
-             stride, ptr(ws), ws.numel() * 4, tag, stream())
+        call("vqa_conv3x3_wgrad_x3", ptr(x), packed, ptr(dpooled), ptr(dpooled_packed) if dpooled_packed is not None else None,
+             ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co, stride, ptr(ws), ws.numel() * 4, tag, stream())
         return
     call("vqa_conv3x3_wgrad", ptr(x), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, CiP, Ci, Co, stride,
          ptr(ws), ws.numel() * 4, tag, stream())

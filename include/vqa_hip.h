@@ -323,12 +323,15 @@ int vqa_conv3x3_relu_pool_fwd_x3(const void* x, int x_packed, const void* wf_pla
                                  int pooled_packed /* 1: the output is written x3-packed, for the next block */,
                                  uint8_t* argmax, int B, int H, int W, int CiP, int Co, int stride, int tag,
                                  vqa_stream_t stream);
-int vqa_conv3x3_dgrad_x3(const float* dpooled, const uint8_t* argmax, const void* wd_planes, float* dx, int B, int H, int W,
-                         int CiP, int Co, int stride, int tag, vqa_stream_t stream);
+/* dpooled: fp32 (dp_packed = 0) or x3-packed (1): the arg-max routing then is a mask on the packed halves */
+int vqa_conv3x3_dgrad_x3(const void* dpooled, int dp_packed, const uint8_t* argmax, const void* wd_planes, float* dx, int B,
+                         int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream);
 int64_t vqa_conv3x3_wgrad_x3_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride);
-int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, const uint8_t* argmax, float* dw,
-                         float* dbias, int B, int H, int W, int CiP, int Ci, int Co, int stride, float* workspace,
-                         int64_t workspace_bytes, int tag, vqa_stream_t stream);
+/* dpooled (fp32) always: the bias gradient is summed from it; dpooled_packed (optional): the same gradient x3-packed,
+ * read by the contraction instead */
+int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, const void* dpooled_packed,
+                         const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W, int CiP, int Ci, int Co,
+                         int stride, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
 /* ---- optimiser: torch.optim.Adam defaults over one flat buffer (train.py:55,80) ------------- */
 int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -89,6 +89,16 @@ def test_conv_x3_matches_float64_like_native_fp32(B, H, W, Ci, Co, stride):
             torch.cuda.synchronize()
             assert torch.equal(pooled_p, pooled) and torch.equal(amax_p, amax)
             assert torch.equal(dw_p, dw) and torch.equal(db_p, db)
+            # x3-packed pooled gradient (routing as a mask on the packed halves): bit-identical again
+            dyp = ops.x3_pack(dyd)
+            dx_p = ops.conv_dgrad(dyp, am, wdx, xd.shape, stride, x3=True)
+            dw_q, db_q = torch.empty_like(dw), torch.empty_like(db)
+            ops.conv_wgrad(xp, dyd, am, dw_q, db_q, stride, x3=True, dpooled_packed=dyp)
+            dw_r, db_r = torch.empty_like(dw), torch.empty_like(db)
+            ops.conv_wgrad(xd, dyd, am, dw_r, db_r, stride, x3=True, dpooled_packed=dyp)
+            torch.cuda.synchronize()
+            assert torch.equal(dx_p, dx)
+            assert torch.equal(dw_q, dw) and torch.equal(db_q, db) and torch.equal(dw_r, dw)
             # output written x3-packed by the epilogue == vqa_x3_pack of the fp32 output, bit for bit
             pooled_q, amax_q = ops.conv_fwd(xp, wfx, b.to(DEV), stride, x3=True, out_packed=True)
             torch.cuda.synchronize()

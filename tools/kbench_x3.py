@@ -46,6 +46,7 @@ def main():
         dw, db = torch.empty_like(w), torch.empty_like(b)
         dx = torch.empty_like(x)
         xp = ops.x3_pack(x)
+        dpp = ops.x3_pack(dp)
         t_pack = timeit(lambda: ops.x3_pack(x), args.iters)
         print(f"conv{l} input x3_pack {t_pack:.3f} ms", flush=True)
         for name, fn in (("fwd", lambda x3: ops.conv_fwd(x, wfx if x3 else wf, b, 1, x3=x3)),
@@ -53,8 +54,10 @@ def main():
                          ("wgrad", lambda x3: ops.conv_wgrad(x, dp, am, dw, db, 1, x3=x3))):
             t = {x3: timeit(lambda: fn(x3), args.iters) for x3 in (False, True)}
             tf = {k: flops / v / 1e9 for k, v in t.items()}
-            if name != "dgrad":
-                fp = (lambda: ops.conv_fwd(xp, wfx, b, 1, x3=True)) if name == "fwd" else (lambda: ops.conv_wgrad(xp, dp, am, dw, db, 1, x3=True))
+            if True:
+                fp = {"fwd": lambda: ops.conv_fwd(xp, wfx, b, 1, x3=True),
+                      "wgrad": lambda: ops.conv_wgrad(xp, dp, am, dw, db, 1, x3=True, dpooled_packed=dpp),
+                      "dgrad": lambda: ops.conv_dgrad(dpp, am, wdx, x.shape, 1, out=dx, x3=True)}[name]
                 tp = timeit(fp, args.iters)
                 print(f"conv{l}_{name:6s} packed input: {tp:7.3f} ms {flops / tp / 1e9:6.1f} TF   x{t[False] / tp:.2f}", flush=True)
             print(f"conv{l}_{name:6s} fp32-MFMA {t[False]:7.3f} ms {tf[False]:6.1f} TF ({100 * tf[False] / 157.3:4.1f}%)   "

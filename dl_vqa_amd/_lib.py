@@ -27,6 +27,9 @@ PROTOTYPES = {
     "vqa_gemm_workspace_bytes": (i64, [i32, i32, i32]),
     "vqa_gemm": (i32, [f32p, i64, i32, f32p, i64, i32, f32p, i64, i32, i32, i32, f32p, f32p,
                        f32p, i64, i32, i32, i32, i32, f32p, f32p, i64, i32, vp]),
+    "vqa_gemm_x3": (i32, [f32p, i64, i32, f32p, i64, i32, f32p, i64, i32, i32, i32, f32p, f32p,
+                       f32p, i64, i32, i32, i32, i32, f32p, f32p, i64, i32, vp]),
+    "vqa_gemm_x3_workspace_bytes": (i64, [i32, i32, i32]),
     "vqa_nchw_to_nhwc4": (i32, [f32p, f32p, i32, i32, i32, i32, vp]),
     "vqa_conv_pack_weights": (i32, [f32p, f32p, f32p, i32, i32, i32, vp]),
     "vqa_conv3x3_relu_pool_fwd": (i32, [f32p, f32p, f32p, f32p, u8p, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvqa_hip.so")
-SOURCES = ["gemm.hip", "conv.hip", "conv0.hip", "lstm.hip", "elementwise.hip", "bf16.hip", "conv_bf16.hip", "conv_x3.hip"]
+SOURCES = ["gemm.hip", "conv.hip", "conv0.hip", "lstm.hip", "elementwise.hip", "bf16.hip", "conv_bf16.hip", "conv_x3.hip", "gemm_x3.hip"]
 HEADERS = ["common.hpp", "gemm_core.hpp", "gemm_epilogue.hpp", "bf16_core.hpp", "x3_core.hpp", "conv_device.inc", "conv_host.inc", "conv_bf16.inc", os.path.join("..", "..", "include", "vqa_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

@@ -79,6 +79,12 @@ class Engine:
         """fp32x3 mode: does this conv block (NHWC input shape, output channels) run on the split kernels?"""
         return self.x3 and len(x_shape) == 4 and ops.conv_x3_supported(x_shape[1], x_shape[2], x_shape[3], Co, self.stride)
 
+    def _x3_gemm(self, rows) -> bool:
+        """fp32x3 mode: the three v_conv products (rows = B * positions) run on the split GEMM when they are large
+        enough to fill the chip with 192 x 128 tiles."""
+        return (self.x3 and rows >= 192 * 64 and self.mid >= 128 and self.C >= 64
+                and os.environ.get("VQA_X3_GEMM", "1") != "0")
+
     def _out_shape(self, x, l, fast0):
         """NHWC shape of block l's pooled output for input activation x (the NCHW image for the dedicated first block)."""
         B, H, W = (x.shape[0], x.shape[2], x.shape[3]) if (l == 0 and fast0) else ops.nhwc_shape(x)[:3]
@@ -292,7 +298,7 @@ class Engine:
                           rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, aux=vprime, tag=21)
         else:
             ops.gemm(v_in, P["attention.v_conv.weight"], xs, B * Pn, mid, C, rowgroup=(qp if mode != 2 else None),
-                     rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, aux=vprime, tag=21)
+                     rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, aux=vprime, tag=21, x3=self._x3_gemm(B * Pn))
         wx = P["attention.x_conv.weight"]
         score = ops.att_score_fwd(xs, wx.view(G, -1), P["attention.x_conv.bias"], B, Pn, p_att, sd(SITE_ATT_X),
                                   qcat=(qp if mode == 2 else None))
@@ -384,14 +390,15 @@ class Engine:
                 ops.gemm_bf16(dx16, ctx.wv16, dvn.view(B * Pn, C), B * Pn, C, mid, transB=False, lda=mid, ldb=C,
                               accumulate=True, tag=45)
         else:
+            gx3 = self._x3_gemm(B * Pn)
             ops.gemm(dxpre, ctx.v_in, Gr["attention.v_conv.weight"], mid, C, B * Pn, transA=True, transB=False, lda=mid,
-                     ldb=C, tag=44)
+                     ldb=C, tag=44, x3=gx3)
             if ctx.p_att > 0:       # dvn += dropout-mask * (dx' . Wv): one pass joins the two branches
                 dv_in = new(B * Pn, C)
-                ops.gemm(dxpre, wv, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
+                ops.gemm(dxpre, wv, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45, x3=gx3)
                 ops.dropout_add(dv_in, dvn, ctx.p_att, sd(SITE_ATT_V))
             else:
-                ops.gemm(dxpre, wv, dvn, B * Pn, C, mid, transB=False, lda=mid, ldb=C, accumulate=True, tag=45)
+                ops.gemm(dxpre, wv, dvn, B * Pn, C, mid, transB=False, lda=mid, ldb=C, accumulate=True, tag=45, x3=gx3)
         ops.gemm(dqp, ctx.q_in, Gr["attention.q_lin.weight"], mid, Q, B, transA=True, transB=False, lda=mid,
                  ldb=ctx.ld_q, tag=46)
         ops.colsum(dqp, B, mid, Gr["attention.q_lin.bias"])

@@ -32,15 +32,16 @@ def _chk(t: torch.Tensor, dtype=torch.float32):
 
 def gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, *, transA=False,
          transB=True, lda=None, ldb=None, ldc=None, bias1=None, bias2=None, rowgroup=None, rg_div=1,
-         rg_op=0, relu=False, accumulate=False, aux=None, tag=0) -> torch.Tensor:
-    """C[M,N] = act(op(A) op(B) (op) rowgroup + bias) (+C).  Leading dims default to the stored row length."""
+         rg_op=0, relu=False, accumulate=False, aux=None, tag=0, x3=False) -> torch.Tensor:
+    """C[M,N] = act(op(A) op(B) (op) rowgroup + bias) (+C).  Leading dims default to the stored row length.
+    x3: the contraction on the bf16 matrix cores with exact 3 x bf16 operand splits (csrc/x3_core.hpp)."""
     lib = _lib.load()
     lda = lda if lda is not None else (M if transA else K)
     ldb = ldb if ldb is not None else (K if transB else N)
     ldc = ldc if ldc is not None else N
-    nbytes = lib.vqa_gemm_workspace_bytes(M, N, K)
+    nbytes = (lib.vqa_gemm_x3_workspace_bytes if x3 else lib.vqa_gemm_workspace_bytes)(M, N, K)
     ws = workspace(nbytes, A.device) if nbytes else None
-    call("vqa_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(C), ldc, M, N, K,
+    call("vqa_gemm_x3" if x3 else "vqa_gemm", ptr(A), lda, int(transA), ptr(B), ldb, int(transB), ptr(C), ldc, M, N, K,
          ptr(bias1), ptr(bias2), ptr(rowgroup), (rowgroup.stride(0) if rowgroup is not None else 0),
          rg_div, rg_op, int(relu), int(accumulate), ptr(aux), ptr(ws), (ws.numel() * 4 if ws is not None else 0),
          tag, stream())

@@ -333,6 +333,14 @@ int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, cons
                          const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W, int CiP, int Ci, int Co,
                          int stride, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
+/* vqa_gemm on the split kernels: the same arguments and results contract (large contractions: the attention stage's
+ * v_conv forward / dW / dX); 192 x 128 tiles, split-K slabs in `workspace` when the output has few tiles. */
+int64_t vqa_gemm_x3_workspace_bytes(int M, int N, int K);
+int vqa_gemm_x3(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C, int64_t ldc,
+                int M, int N, int K, const float* bias1, const float* bias2, const float* rowgroup, int64_t rg_ld,
+                int rg_div, int rg_op, int relu, int accumulate, float* aux, float* workspace, int64_t workspace_bytes,
+                int tag, vqa_stream_t stream);
+
 /* ---- optimiser: torch.optim.Adam defaults over one flat buffer (train.py:55,80) ------------- */
 int vqa_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
              float beta1, float beta2, float eps, int step, float grad_scale, vqa_stream_t stream);

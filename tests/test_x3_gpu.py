@@ -175,3 +175,52 @@ def test_fp32x3_module_uses_packed_activations_and_matches_fp32_module():
         # 1e-3 as test_train_mode_full224_matches_oracle_with_shared_masks: the first block's weight gradient sums 1e7
         # products per element behind two arg-max routings, where a tie broken the other way moves it by ~1e-4
         assert e < 1e-3, (k, e)
+
+
+@pytest.mark.parametrize("M,N,K", [(1352, 1024, 256), (1024, 256, 5000), (700, 256, 1024), (200, 130, 70)])
+@pytest.mark.parametrize("transA,transB", [(False, True), (False, False), (True, True), (True, False)])
+def test_gemm_x3_layouts(M, N, K, transA, transB):
+    """vqa_gemm_x3 in the four operand layouts (tails in M, N, K; split-K slabs for the few-tile shapes) against
+    float64, beside vqa_gemm on the same operands."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    lda = (M if transA else K) + 3 & ~3
+    ldb = (K if transB else N) + 3 & ~3
+    A = torch.randn((K, lda) if transA else (M, lda), generator=g)
+    Bm = torch.randn((N, ldb) if transB else (K, ldb), generator=g)
+    A2 = (A[:, :M].t() if transA else A[:, :K]).double()
+    B2 = (Bm[:, :K].t() if transB else Bm[:, :N]).double()
+    ref = A2 @ B2
+    out = {}
+    for x3 in (False, True):
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(DEV), Bm.to(DEV), C, M, N, K, transA=transA, transB=transB, lda=lda, ldb=ldb, x3=x3)
+        torch.cuda.synchronize()
+        out[x3] = rel_err(C, ref)
+    print(f"[parity-x3] gemm {M}x{N}x{K} tA={transA} tB={transB}: fp32-MFMA err {out[False]:.3e}, 3xbf16 err {out[True]:.3e}")
+    assert out[True] < 2e-6 * math.sqrt(K / 256 + 1) and out[True] < 2.0 * out[False] + 2e-7
+
+
+def test_gemm_x3_epilogue():
+    """The v_conv forward form: row-group term tiled over positions (add / multiply), bias, ReLU, raw-product output,
+    accumulate -- the fp32 engine's epilogue on the split kernel's accumulators."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    Bn, Pn, C, mid = 3, 676, 256, 384
+    M = Bn * Pn
+    A, W = torch.randn(M, C, generator=g), torch.randn(mid, C, generator=g) * 0.1
+    qp, bias = torch.randn(Bn, mid, generator=g), torch.randn(mid, generator=g)
+    raw = A.double() @ W.double().t()
+    for op in (0, 1):
+        tiled = qp.double().repeat_interleave(Pn, dim=0)
+        ref = torch.relu((raw * tiled if op else raw + tiled) + bias.double())
+        C1, aux = torch.empty(M, mid, device=DEV), torch.empty(M, mid, device=DEV)
+        ops.gemm(A.to(DEV), W.to(DEV), C1, M, mid, C, rowgroup=qp.to(DEV), rg_div=Pn, rg_op=op, bias1=bias.to(DEV), relu=True,
+                 aux=aux, x3=True)
+        torch.cuda.synchronize()
+        assert rel_err(C1, ref) < 3e-6 and rel_err(aux, raw) < 3e-6
+    acc0 = torch.randn(M, mid, generator=g)
+    C2 = acc0.clone().to(DEV)
+    ops.gemm(A.to(DEV), W.to(DEV), C2, M, mid, C, accumulate=True, x3=True)
+    torch.cuda.synchronize()
+    assert rel_err(C2, raw + acc0.double()) < 3e-6

@@ -66,5 +66,29 @@ def main():
         x = pooled
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--gemm" not in sys.argv:
     main()
+
+
+def gemms():
+    """the three v_conv products at the headline shape: fp32 MFMA vs split kernel"""
+    dev = "cuda:0"
+    Bn, Pn, C, mid = 256, 676, 256, 1024
+    M = Bn * Pn
+    v = torch.randn(M, C, device=dev)
+    w = torch.randn(mid, C, device=dev) * 0.05
+    qp = torch.randn(Bn, mid, device=dev)
+    xs = torch.empty(M, mid, device=dev)
+    dxp = torch.randn(M, mid, device=dev)
+    dw = torch.empty(mid, C, device=dev)
+    dv = torch.empty(M, C, device=dev)
+    fl = 2.0 * M * C * mid
+    for name, fn in (("v_conv fwd", lambda x3: ops.gemm(v, w, xs, M, mid, C, rowgroup=qp, rg_div=Pn, relu=True, x3=x3)),
+                     ("v_conv dW", lambda x3: ops.gemm(dxp, v, dw, mid, C, M, transA=True, transB=False, lda=mid, ldb=C, x3=x3)),
+                     ("v_conv dX", lambda x3: ops.gemm(dxp, w, dv, M, C, mid, transB=False, lda=mid, ldb=C, x3=x3))):
+        t = {x3: timeit(lambda: fn(x3), 5) for x3 in (False, True)}
+        print(f"{name:12s} fp32-MFMA {t[False]:7.3f} ms {fl / t[False] / 1e9:6.1f} TF   3xbf16 {t[True]:7.3f} ms {fl / t[True] / 1e9:6.1f} TF   x{t[False] / t[True]:.2f}", flush=True)
+
+
+if __name__ == "__main__" and "--gemm" in sys.argv:
+    gemms()

@@ -3,6 +3,7 @@
 # configs[4] in both fp32 modes, RCCL ws=1), rocprofv3 kernel stats and PMC passes.  Every step under its own timeout.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
 T="timeout -k 10"
+$T 300 python bench.py --dtype fp32x3 --batch 1024 --tokens 30 --answers 3000 --steps 4 --warmup 2 --no-cpu-baseline > $O/r02_bench_stress_fp32x3.json 2> $O/r02_bench_stress_fp32x3.err; head -c 300 $O/r02_bench_stress_fp32x3.json; echo
 cd /tmp; export TMPDIR=/tmp
 rm -rf $O/r02_pmc_*
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do

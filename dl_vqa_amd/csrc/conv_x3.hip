@@ -339,6 +339,53 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename A
   else conv_pool_epilogue<Cfg>(acc, bias, pooled, amax, pa.nWin, Co, m0, n0, wm, wn, lane);
 }
 
+// persistent variants: one workgroup per CU walks the tiles, the loaders run ahead into the next tile during the epilogue
+template <class Cfg, class AL, bool OP>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_persistent_kernel(typename AL::Params pa,
+                                                                                 typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
+                                                                                 const float* __restrict__ bias, void* pooled,
+                                                                                 uint8_t* amax, int Co, int tiles_m, int tiles_n,
+                                                                                 int nk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  using BL = PlainCx<Cfg::NVB, Cfg::LT>;
+  gemm_persistent_x<Cfg, AL, BL>(
+      xcd_swizzle(blockIdx.x, gridDim.x), gridDim.x, tiles_m * tiles_n, nk, smem,
+      [&](int t, AL& al, BL& bl) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        al.init(pa, mt * Cfg::BM, loader_tid<Cfg>(), 0);
+        bl.init(pb, nt * Cfg::BN, loader_tid<Cfg>(), 0);
+      },
+      [&](int t, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        if constexpr (OP) conv_pool_epilogue_x3p<Cfg>(acc, bias, pooled, amax, pa.nWin, Co, mt * Cfg::BM, nt * Cfg::BN, wm, wn, lane);
+        else conv_pool_epilogue<Cfg>(acc, bias, pooled, amax, pa.nWin, Co, mt * Cfg::BM, nt * Cfg::BN, wm, wn, lane);
+      });
+}
+
+template <class Cfg, class AL>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_persistent_kernel(typename AL::Params pa,
+                                                                                   typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
+                                                                                   float* dx, int CiP, int tiles_m, int tiles_n,
+                                                                                   int nk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  using BL = PlainCx<Cfg::NVB, Cfg::LT>;
+  gemm_persistent_x<Cfg, AL, BL>(
+      xcd_swizzle(blockIdx.x, gridDim.x), gridDim.x, tiles_m * tiles_n, nk, smem,
+      [&](int t, AL& al, BL& bl) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        al.init(pa, mt * Cfg::BM, loader_tid<Cfg>(), 0);
+        bl.init(pb, nt * Cfg::BN, loader_tid<Cfg>(), 0);
+      },
+      [&](int t, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        store_acc_tiles<Cfg>(acc, dx, CiP, pa.rows, CiP, mt * Cfg::BM, nt * Cfg::BN, wm, wn, lane);
+      });
+}
+
 template <class Cfg, class AL>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename AL::Params pa,
                                                                         typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
@@ -393,6 +440,16 @@ static int launch_fwd_x3(const void* x, const void* wf, const float* bias, void*
   typename AL::Params pa{static_cast<decltype(AL::Params::x)>(x), g.H, g.W, g.CiP, g.Hp, g.Wp, g.stride, nWin, K};
   typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb{wf, g.Co, g.Co, K, (int64_t)K * g.Co};
   const int tiles_m = (4 * nWin + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.Co + Cfg::BN - 1) / Cfg::BN;
+  // one workgroup per CU: nothing else covers a tile's prologue and epilogue, so the tiles are walked persistently
+  // (VQA_PERSISTENT=0 selects one workgroup per tile)
+  const int tiles = tiles_m * tiles_n;
+  if (knobs().persistent != 0 && tiles > 256) {
+    auto pk = conv_fwd_x3_persistent_kernel<Cfg, AL, OP>;
+    { int rc = set_smem(pk, SL::BYTES, "attr(conv_fwd_x3_p)"); if (rc) return rc; }
+    hipLaunchKernelGGL(pk, dim3(256), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, bias, pooled, amax, g.Co, tiles_m, tiles_n,
+                       K / BK);
+    return check_hip(hipGetLastError(), "conv_fwd_x3_persistent launch");
+  }
   auto kern = conv_fwd_x3_kernel<Cfg, AL, OP>;
   { int rc = set_smem(kern, SL::BYTES, "attr(conv_fwd_x3)"); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, bias, pooled, amax, g.Co,
@@ -408,6 +465,13 @@ static int launch_dgrad_x3(const void* dp, const uint8_t* am, const void* wd, fl
   typename AL::Params pa{static_cast<decltype(AL::Params::dp)>(dp), am, g.H, g.W, g.Hp, g.Wp, g.Co, g.stride, rows, K};
   typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb{wd, g.CiP, g.CiP, K, (int64_t)K * g.CiP};
   const int tiles_m = (rows + Cfg::BM - 1) / Cfg::BM, tiles_n = (g.CiP + Cfg::BN - 1) / Cfg::BN;
+  const int tiles = tiles_m * tiles_n;
+  if (knobs().persistent != 0 && tiles > 256) {      // see launch_fwd_x3
+    auto pk = conv_dgrad_x3_persistent_kernel<Cfg, AL>;
+    { int rc = set_smem(pk, SL::BYTES, "attr(conv_dgrad_x3_p)"); if (rc) return rc; }
+    hipLaunchKernelGGL(pk, dim3(256), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, dx, g.CiP, tiles_m, tiles_n, K / BK);
+    return check_hip(hipGetLastError(), "conv_dgrad_x3_persistent launch");
+  }
   auto kern = conv_dgrad_x3_kernel<Cfg, AL>;
   { int rc = set_smem(kern, SL::BYTES, "attr(conv_dgrad_x3)"); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, dx, g.CiP, tiles_m,

@@ -202,29 +202,37 @@ __device__ __forceinline__ void loader_loop_x(AL& al, BL& bl, int ks0, int ks1, 
 // ---------------------------------------------------------------- MFMA role
 // One K-step = 2 groups m = 0, 1 of 6 * TM * TN MFMAs; the fragments of the next group are fetched before the MFMAs of
 // the current one; the K-step barrier sits in front of the last group (every fragment of the stage is in registers).
+// Fragment reads of one group go in two parts, A and B: each part stays below the 15 operations lgkmcnt can count, so the
+// wait in front of an MFMA block covers exactly the reads it consumes (with all 21 reads of a group issued at once the
+// compiler had to wait for the 7 oldest of the NEW reads too: ~200 exposed cycles per group).
 template <class Cfg, bool AR, bool BR>
-__device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1, const float* smem) {
+struct MfmaX {
   using SL = SmemLayoutX<Cfg, AR, BR>;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-  const int l31 = lane & 31, h = lane >> 5, i16 = lane & 15, grp = (lane >> 4) & 1;
-  constexpr int RSA = LdsImageX<Cfg::BM>::RSB, RSBb = LdsImageX<Cfg::BN>::RSB;
-  constexpr int PLA = AR ? Cfg::BM * XRS * 4 : LdsImageX<Cfg::BM>::PLANE;     // plane stride, bytes
-  constexpr int PLB = BR ? Cfg::BN * XRS * 4 : LdsImageX<Cfg::BN>::PLANE;
-  const int a_off = AR ? ((wm * Cfg::WM + l31) * XRS + 4 * h) * 4
-                       : (8 * h + (i16 >> 2)) * RSA + (wm * Cfg::WM + 16 * grp + 4 * (i16 & 3)) * 2;
-  const int b_off = BR ? ((wn * Cfg::WN + l31) * XRS + 4 * h) * 4
-                       : (8 * h + (i16 >> 2)) * RSBb + (wn * Cfg::WN + 16 * grp + 4 * (i16 & 3)) * 2;
-  const char* const sm = reinterpret_cast<const char*>(smem);
-  const char* const As0 = sm + a_off;
-  const char* const Bs0 = sm + 2 * SL::ABUF * 4 + b_off;
+  static constexpr int RSA = LdsImageX<Cfg::BM>::RSB, RSBb = LdsImageX<Cfg::BN>::RSB;
+  static constexpr int PLA = AR ? Cfg::BM * XRS * 4 : LdsImageX<Cfg::BM>::PLANE;     // plane stride, bytes
+  static constexpr int PLB = BR ? Cfg::BN * XRS * 4 : LdsImageX<Cfg::BN>::PLANE;
+  const char* As0;
+  const char* Bs0;
   bf16x8 a[2][3][Cfg::TM], b[2][3][Cfg::TN];
-  auto trread = [](const char* p) -> s16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p)); };
-  // fragment reads of one group, A part and B part separately: each part stays below the 15 operations lgkmcnt can
-  // count, so the wait in front of an MFMA block covers exactly the reads it consumes (with all 21 reads of a group
-  // issued at once the compiler had to wait for the 7 oldest of the NEW reads too: ~200 exposed cycles per group)
-  auto fetchA = [&](const char* ap, int m, int buf) {
+
+  __device__ __forceinline__ void setup(const float* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int l31 = lane & 31, h = lane >> 5, i16 = lane & 15, grp = (lane >> 4) & 1;
+    const int a_off = AR ? ((wm * Cfg::WM + l31) * XRS + 4 * h) * 4
+                         : (8 * h + (i16 >> 2)) * RSA + (wm * Cfg::WM + 16 * grp + 4 * (i16 & 3)) * 2;
+    const int b_off = BR ? ((wn * Cfg::WN + l31) * XRS + 4 * h) * 4
+                         : (8 * h + (i16 >> 2)) * RSBb + (wn * Cfg::WN + 16 * grp + 4 * (i16 & 3)) * 2;
+    const char* const sm = reinterpret_cast<const char*>(smem);
+    As0 = sm + a_off;
+    Bs0 = sm + 2 * SL::ABUF * 4 + b_off;
+  }
+  static __device__ __forceinline__ s16x4 trread(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  }
+  __device__ __forceinline__ void fetchA(int stage, int m, int buf) {
+    const char* ap = As0 + stage * SL::ABUF * 4;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -238,8 +246,9 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
           a[buf][pl][i] = __builtin_bit_cast(bf16x8, v);
         }
       }
-  };
-  auto fetchB = [&](const char* bp, int m, int buf) {
+  }
+  __device__ __forceinline__ void fetchB(int stage, int m, int buf) {
+    const char* bp = Bs0 + stage * SL::BBUF * 4;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -253,13 +262,13 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
           b[buf][pl][j] = __builtin_bit_cast(bf16x8, v);
         }
       }
-  };
+  }
   // plane pairs, small terms first: (lo,hi) (hi,lo) (mid,mid) | (mid,hi) (hi,mid) (hi,hi); consecutive MFMAs go to
   // different accumulators
-  auto mma = [&](int buf, auto half) {
+  template <int H>
+  __device__ __forceinline__ void mma(f32x16 (&acc)[Cfg::TM][Cfg::TN], int buf) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-    constexpr int H = decltype(half)::value;
 #ifdef VQA_X3_EXP_NPROD     // timing experiment: only the last NPROD partial products
     constexpr int T0 = 6 - VQA_X3_EXP_NPROD;
 #else
@@ -274,35 +283,42 @@ __device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int
         for (int j = 0; j < Cfg::TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[buf][PA[t]][i], b[buf][PB[t]][j], acc[i][j], 0, 0, 0);
     }
-  };
-  constexpr std::integral_constant<int, 0> H0{};
-  constexpr std::integral_constant<int, 1> H1{};
-  __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
-  __syncthreads();
-  fetchA(As0, 0, 0);
-  fetchB(Bs0, 0, 0);
-  for (int ks = ks0; ks < ks1; ++ks) {
-    const int cur = (ks - ks0) & 1;
-    const char* const Ac = As0 + cur * SL::ABUF * 4;
-    const char* const Bc = Bs0 + cur * SL::BBUF * 4;
-    fetchA(Ac, 1, 1);
+  }
+  // first fragments of a stage (group 0 into buffer 0): before the first K-step of a run
+  __device__ __forceinline__ void prime(int stage) {
+    fetchA(stage, 0, 0);
+    fetchB(stage, 0, 0);
+  }
+  // one K-step on stage `cur` (its group 0 already in buffer 0); has_next: the other stage holds a further K-step
+  __device__ __forceinline__ void kstep(f32x16 (&acc)[Cfg::TM][Cfg::TN], int cur, bool has_next) {
+    fetchA(cur, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma(0, H0);
+    mma<0>(acc, 0);
     __builtin_amdgcn_sched_barrier(0);
-    fetchB(Bc, 1, 1);
+    fetchB(cur, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma(0, H1);
+    mma<1>(acc, 0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();   // every fragment of this stage is in registers; the next stage is complete
-    if (ks + 1 < ks1) fetchA(As0 + (cur ^ 1) * SL::ABUF * 4, 0, 0);
+    if (has_next) fetchA(cur ^ 1, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    mma(1, H0);
+    mma<0>(acc, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (ks + 1 < ks1) fetchB(Bs0 + (cur ^ 1) * SL::BBUF * 4, 0, 0);
+    if (has_next) fetchB(cur ^ 1, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    mma(1, H1);
+    mma<1>(acc, 1);
     __builtin_amdgcn_sched_barrier(0);
   }
+};
+
+template <class Cfg, bool AR, bool BR>
+__device__ __forceinline__ void mfma_loop_x(f32x16 (&acc)[Cfg::TM][Cfg::TN], int ks0, int ks1, const float* smem) {
+  MfmaX<Cfg, AR, BR> mx;
+  mx.setup(smem);
+  __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
+  __syncthreads();
+  mx.prime(0);
+  for (int ks = ks0; ks < ks1; ++ks) mx.kstep(acc, (ks - ks0) & 1, ks + 1 < ks1);
 }
 
 // Whole contraction over K-steps [ks0, ks1): true for MFMA waves (they hold the accumulators), false for loader waves.
@@ -317,6 +333,74 @@ __device__ __forceinline__ bool gemm_mainloop_x(Init&& init, f32x16 (&acc)[Cfg::
   }
   mfma_loop_x<Cfg, AL::kTypeR, BL::kTypeR>(acc, ks0, ks1, smem);
   return true;
+}
+
+// ---------------------------------------------------------------- persistent tiles
+// As gemm_persistent (gemm_core.hpp): a workgroup walks the tiles first, first + stride, ... (< ntiles), every tile the
+// same K-steps [0, nk); the loader waves treat them as one flat sequence of K-steps, so the first stages of tile t+1 are
+// loaded, split and in LDS while the MFMA waves run the epilogue of tile t.  With ONE workgroup per CU there is no second
+// workgroup to cover a tile's prologue and epilogue, which is what this buys back.
+//   init_tile(tile, AL&, BL&)  : (re)initialise both loaders for a tile;   epilogue(tile, acc) : MFMA waves, no barriers
+template <class Cfg, class AL, class BL, class InitTile, class Epilogue>
+__device__ __forceinline__ void gemm_persistent_x(int first, int stride, int ntiles, int nk, float* smem,
+                                                  InitTile&& init_tile, Epilogue&& epilogue) {
+  using SL = SmemLayoutX<Cfg, AL::kTypeR, BL::kTypeR>;
+  constexpr int D = Cfg::PREFETCH;
+  if (first >= ntiles) return;
+  const int my_tiles = (ntiles - first + stride - 1) / stride;
+  const int total = my_tiles * nk;
+  if (is_loader_wave<Cfg>()) {
+    const int ltid = loader_tid<Cfg>();
+    const SplitConsts kc = split_consts();
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * SL::ABUF;
+    AL al; BL bl;
+    typename AL::Raw rawA[D];
+    typename BL::Raw rawB[D];
+    int tile = first, ks = 0;            // the K-step the next issue() fetches
+    init_tile(tile, al, bl);
+    auto next = [&](typename AL::Raw& ra, typename BL::Raw& rb) {   // issue K-step (tile, ks), advance across tile seams
+      if (ks == nk) {
+        ks = 0;
+        if (tile + stride < ntiles) tile += stride;     // past the last tile: harmless refetch, never read
+        init_tile(tile, al, bl);
+      }
+      al.issue(ks, ra);
+      bl.issue(ks, rb);
+      ++ks;
+    };
+    next(rawA[0], rawB[0]);
+    stage_store_x<Cfg, AL, true>(al, rawA[0], As0, ltid, kc);
+    stage_store_x<Cfg, BL, false>(bl, rawB[0], Bs0, ltid, kc);
+#pragma unroll
+    for (int d = 0; d < D; ++d) next(rawA[d], rawB[d]);
+    __syncthreads();
+    for (int s = 0; s < total; s += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (s + d < total) {
+          const int nxt = ((s + d) & 1) ^ 1;
+          stage_store_x<Cfg, AL, true>(al, rawA[d], As0 + nxt * SL::ABUF, ltid, kc);
+          stage_store_x<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid, kc);
+          next(rawA[d], rawB[d]);
+          __syncthreads();
+        }
+      }
+    }
+    return;
+  }
+  MfmaX<Cfg, AL::kTypeR, BL::kTypeR> mx;
+  mx.setup(smem);
+  __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
+  __syncthreads();
+  mx.prime(0);
+  int s = 0;
+  for (int tile = first; tile < ntiles; tile += stride) {
+    f32x16 acc[Cfg::TM][Cfg::TN];
+    acc_zero<Cfg>(acc);
+    for (int ks = 0; ks < nk; ++ks, ++s) mx.kstep(acc, s & 1, s + 1 < total);
+    epilogue(tile, acc);
+  }
 }
 
 }  // namespace vqa

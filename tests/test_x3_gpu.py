@@ -41,6 +41,19 @@ def test_split_is_exact():
     assert bool((lo.double().abs() <= hi.double().abs() * 2.0 ** -16).all())
 
 
+@pytest.fixture
+def knob(monkeypatch):
+    """Set a VQA_* knob for one test (the library reads them once: vqa_reload_knobs after every change)."""
+    from dl_vqa_amd import _lib
+
+    def set_knob(name, value):
+        monkeypatch.setenv(name, value)
+        _lib.load().vqa_reload_knobs()
+    yield set_knob
+    monkeypatch.undo()
+    _lib.load().vqa_reload_knobs()
+
+
 X3_CASES = [  # B, H, W, Ci, Co, stride
     (2, 58, 58, 64, 128, 1),   # conv1 family: 192x128 tiles forward / wgrad, 256x64 dgrad
     (1, 38, 38, 128, 256, 1),  # conv2 family
@@ -48,6 +61,7 @@ X3_CASES = [  # B, H, W, Ci, Co, stride
     (2, 38, 42, 32, 96, 1),    # partial N tile (Co = 96), one K-step per tap
     (2, 69, 73, 32, 64, 2),    # stride 2
     (5, 36, 36, 96, 160, 1),   # three K-steps per tap, 1.25 N tiles, rows % 192 != 0
+    (4, 122, 122, 96, 128, 1), # > 256 tiles: the persistent forward / dgrad kernels (tile seams, uneven tile counts)
 ]
 
 
@@ -224,3 +238,30 @@ def test_gemm_x3_epilogue():
     ops.gemm(A.to(DEV), W.to(DEV), C2, M, mid, C, accumulate=True, x3=True)
     torch.cuda.synchronize()
     assert rel_err(C2, raw + acc0.double()) < 3e-6
+
+
+def test_persistent_tiles_equal_one_workgroup_per_tile(knob):
+    """Forward and dgrad of a layer with more than 256 tiles run as persistent workgroups (the loaders run ahead into the
+    next tile during the epilogue); VQA_PERSISTENT=0 selects one workgroup per tile: same arithmetic, identical bits."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    B, H, W, Ci, Co = 3, 150, 142, 64, 128
+    x = torch.randn(B, H, W, Ci, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).to(DEV)
+    b = (torch.randn(Co, generator=g) * 0.1).to(DEV)
+    wf, wd = ops.conv_pack_weights(w, Ci)
+    wfx, wdx, xp = ops.x3_split(wf), ops.x3_split(wd), ops.x3_pack(x)
+    out = {}
+    for mode in ("default", "0"):
+        if mode == "0":
+            knob("VQA_PERSISTENT", "0")
+        pooled, am = ops.conv_fwd(xp, wfx, b, 1, x3=True)
+        pooled_p, _ = ops.conv_fwd(x, wfx, b, 1, x3=True, out_packed=True)
+        dp = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        dx = ops.conv_dgrad(ops.x3_pack(dp), am, wdx, x.shape, 1, x3=True)
+        dx2 = ops.conv_dgrad(dp, am, wdx, x.shape, 1, x3=True)
+        torch.cuda.synchronize()
+        out[mode] = (pooled, am, pooled_p, dx, dx2)
+    for a, c in zip(out["default"], out["0"]):
+        assert torch.equal(a, c)
+    assert torch.equal(out["default"][3], out["default"][4])

@@ -264,6 +264,9 @@ def main():
         x3_info = {"value": round(B * world * args.steps / el_x, 2), "unit": "samples/s",
                    "ms_per_step": round(el_x / args.steps * 1e3, 3), "steps": args.steps, "warmup": args.warmup,
                    "final_loss": round(float(loss_x.detach()), 5),
+                   # the step's fp32 FLOPs per second against the fp32 MFMA peak (what the native path is priced against)
+                   "step_frac_of_fp32_mfma_peak": round(B * world * args.steps / el_x * step_flops_per_sample(cfg, S, T) / 1e12
+                                                        / (FP32_MFMA_PEAK_TFLOPS * world), 4),
                    "dtype": "f32 (3xbf16 split on bf16 MFMA, fp32 accumulate)",
                    "note": "same step, batch and weights; conv blocks 1.. and the v_conv products on the bf16 matrix cores with "
                            "every fp32 operand split exactly into three bf16 terms (six partial products, fp32 accumulate): "

@@ -5,10 +5,6 @@
 
 namespace vqa {
 
-int colsum_launch(const float* x, int64_t ld, const uint8_t* mask, int64_t rows, int cols, float* out,
-                  int accumulate, float* ws, int64_t ws_bytes, hipStream_t s);
-int64_t colsum_ws_bytes(int64_t rows, int cols);
-
 #include "conv_device.inc"
 #include "conv_host.inc"
 
@@ -18,6 +14,11 @@ int64_t colsum_ws_bytes(int64_t rows, int cols);
 // one workgroup per CU (240 bytes of LDS per tile row and stage): 4 MFMA waves + 4 loader waves, 256 VGPRs each
 using CfgX = TileCfg<192, 128, 2, 2, 4, VQA_X3_PF>;      // MFMA waves of 96 x 64
 using CfgXn = TileCfg<256, 64, 4, 1, 4, VQA_X3_PF>;      // 64 output columns (conv1 dgrad): MFMA waves of 64 x 64
+// K-steps of loads in flight per kernel family (same box, packed operands, conv1 / conv2 ms): dgrad 1: 2.75 / 1.83, 2: 2.82 /
+// 1.88, 3 spills (5.7 / 2.4); wgrad 1: 2.05 / 1.85, 2: 1.94 / 1.72, 3: 1.89 / 1.67; forward the same at 1, 2 and 3
+using CfgXd = TileCfg<192, 128, 2, 2, 4, 1>;
+using CfgXnd = TileCfg<256, 64, 4, 1, 4, 1>;
+using CfgXw = TileCfg<192, 128, 2, 2, 4, 3>;
 
 // ------------------------------------------------------------------ activations split ahead of time ("x3-packed")
 // An activation tensor [pixels][C] (C % 4 == 0) can be handed over already split, so that the split is done once per
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void conv_bias_grad_kernel(const float* dp, co
   }
 }
 
-// the operand split on its own (tests): planes of n bf16 each
+// the operand split on its own: planes of n bf16 each (the packed weights, once per step; tests)
 __global__ void x3_split_kernel(const float4* x, uint2* hi, uint2* mid, uint2* lo, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) split4(x[i], hi[i], mid[i], lo[i], split_consts());
@@ -633,11 +634,11 @@ int vqa_conv3x3_dgrad_x3(const void* dpooled, int dp_packed, const uint8_t* argm
     const void* dpc = static_cast<const char*>(dpooled) + po * (dp_packed ? 6 : 4);
     hipStream_t st = (hipStream_t)stream;
     if (dp_packed)
-      rc = CiP > 64 ? launch_dgrad_x3<CfgX, ConvDgradAx<CfgX::NVA, CfgX::LT>>(dpc, argmax + po, wd, dx + xo, g, st)
-                    : launch_dgrad_x3<CfgXn, ConvDgradAx<CfgXn::NVA, CfgXn::LT>>(dpc, argmax + po, wd, dx + xo, g, st);
+      rc = CiP > 64 ? launch_dgrad_x3<CfgXd, ConvDgradAx<CfgXd::NVA, CfgXd::LT>>(dpc, argmax + po, wd, dx + xo, g, st)
+                    : launch_dgrad_x3<CfgXnd, ConvDgradAx<CfgXnd::NVA, CfgXnd::LT>>(dpc, argmax + po, wd, dx + xo, g, st);
     else
-      rc = CiP > 64 ? launch_dgrad_x3<CfgX, ConvDgradA<CfgX::NVA, CfgX::LT, true>>(dpc, argmax + po, wd, dx + xo, g, st)
-                    : launch_dgrad_x3<CfgXn, ConvDgradA<CfgXn::NVA, CfgXn::LT, true>>(dpc, argmax + po, wd, dx + xo, g, st);
+      rc = CiP > 64 ? launch_dgrad_x3<CfgXd, ConvDgradA<CfgXd::NVA, CfgXd::LT, true>>(dpc, argmax + po, wd, dx + xo, g, st)
+                    : launch_dgrad_x3<CfgXnd, ConvDgradA<CfgXnd::NVA, CfgXnd::LT, true>>(dpc, argmax + po, wd, dx + xo, g, st);
     if (rc) return rc;
   }
   return VQA_OK;
@@ -673,7 +674,7 @@ int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, cons
   int parts = 0;
   for (int b0 = 0; b0 < B; b0 += chunk)
     parts += plan_wgrad_x3(make_geom(B - b0 < chunk ? B - b0 : chunk, H, W, CiP, Co, stride)).splits;
-  float* const colsum_ws = workspace + (int64_t)parts * KI * Co;
+  float* const bias_parts = workspace + (int64_t)parts * KI * Co;
   hipStream_t s = (hipStream_t)stream;
   set_launch_tag(tag);
   ProfScope prof(VQA_K_CONV_WGRAD, s);
@@ -684,24 +685,24 @@ int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, cons
     rc = check_geom("vqa_conv3x3_wgrad_x3", g);
     if (rc) return rc;
     const WgradPlanX p = plan_wgrad_x3(g);
-    using SL = SmemLayoutX<CfgX, false, false>;
+    using SL = SmemLayoutX<CfgXw, false, false>;
     WgradGeom wg{g.H, g.W, g.CiP, g.Hp, g.Wp, g.Co, g.stride, p.Mtot};
     const int64_t po = (int64_t)b0 * g1.Hp * g1.Wp * Co;
     const char* xc = static_cast<const char*>(x) + (int64_t)b0 * H * W * CiP * (x_packed ? 6 : 4);
     const dim3 grid(p.tiles_m * p.tiles_n * p.splits);
     float* slab = workspace + (int64_t)done * KI * Co;
-    using AF = WgradA<CfgX::NVA, CfgX::LT, true>;
-    using AP = WgradAx<CfgX::NVA, CfgX::LT>;
-    using BF = WgradB<CfgX::NVB, CfgX::LT, true>;
-    using BP = WgradBx<CfgX::NVB, CfgX::LT>;
+    using AF = WgradA<CfgXw::NVA, CfgXw::LT, true>;
+    using AP = WgradAx<CfgXw::NVA, CfgXw::LT>;
+    using BF = WgradB<CfgXw::NVB, CfgXw::LT, true>;
+    using BP = WgradBx<CfgXw::NVB, CfgXw::LT>;
 #define X3_WGRAD(AL, BL, XPTR, DPTR)                                                                                   \
     {                                                                                                                  \
       typename AL::Params pa{XPTR, wg, p.KI};                                                                          \
       typename BL::Params pb{DPTR, argmax + po, wg};                                                                   \
-      auto kern = conv_wgrad_x3_kernel<CfgX, AL, BL>;                                                                  \
+      auto kern = conv_wgrad_x3_kernel<CfgXw, AL, BL>;                                                                  \
       rc = set_smem(kern, SL::BYTES, "attr(conv_wgrad_x3)");                                                           \
       if (rc) return rc;                                                                                               \
-      hipLaunchKernelGGL(kern, grid, dim3(CfgX::THREADS), SL::BYTES, s, pa, pb, slab, p.tiles_m, p.tiles_n, p.nk,      \
+      hipLaunchKernelGGL(kern, grid, dim3(CfgXw::THREADS), SL::BYTES, s, pa, pb, slab, p.tiles_m, p.tiles_n, p.nk,      \
                          p.ks_per_split);                                                                              \
     }
     const float* xf = reinterpret_cast<const float*>(xc);
@@ -725,10 +726,10 @@ int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, cons
   const int nparts = rows < kBiasParts ? (int)rows : kBiasParts;
   const int64_t per = (rows + nparts - 1) / nparts;
   hipLaunchKernelGGL(conv_bias_grad_kernel, dim3(nparts), dim3(256), (size_t)(256 / (Co / 4)) * Co * 4, s, dpooled, argmax,
-                     colsum_ws, rows, Co, per);
+                     bias_parts, rows, Co, per);
   rc = check_hip(hipGetLastError(), "conv_bias_grad launch");
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, colsum_ws, dbias, nparts, Co);
+  hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bias_parts, dbias, nparts, Co);
   return check_hip(hipGetLastError(), "wgrad_bias_reduce launch");
 }
 

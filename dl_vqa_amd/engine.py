@@ -70,6 +70,7 @@ class Engine:
             raise ValueError(f"compute_dtype {compute_dtype!r} (fp32, fp32x3 or bf16)")
         self.bf16 = compute_dtype == "bf16"
         self.x3 = compute_dtype == "fp32x3"
+        self.x3_gemm = self.x3 and os.environ.get("VQA_X3_GEMM", "1") != "0"     # diagnostic switch, read once
         if self.bf16:
             if self.L < 2 or any(ch % 64 for ch in self.channels[1:]) or self.mid % 8 or self.stride != 1:
                 raise ValueError("the bf16 path needs >= 2 conv blocks, stride 1 and channel counts that are multiples "
@@ -82,8 +83,7 @@ class Engine:
     def _x3_gemm(self, rows) -> bool:
         """fp32x3 mode: the three v_conv products (rows = B * positions) run on the split GEMM when they are large
         enough to fill the chip with 192 x 128 tiles."""
-        return (self.x3 and rows >= 192 * 64 and self.mid >= 128 and self.C >= 64
-                and os.environ.get("VQA_X3_GEMM", "1") != "0")
+        return self.x3_gemm and rows >= 192 * 64 and self.mid >= 128 and self.C >= 64
 
     def _out_shape(self, x, l, fast0):
         """NHWC shape of block l's pooled output for input activation x (the NCHW image for the dedicated first block)."""

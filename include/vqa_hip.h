@@ -313,7 +313,8 @@ int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* ar
  * (vqa_x3_split of the fp32 packing, once per step); shapes: CiP, Co multiples of 32 and a conv output
  * row of at least 32 pixels (vqa_conv3x3_x3_supported), other layers keep the fp32 MFMA entry points. */
 int vqa_conv3x3_x3_supported(int H, int W, int CiP, int Co, int stride);
-/* the operand split of those kernels on its own (tests): x[n] -> three planes of n bf16, x == hi + mid + lo exactly */
+/* the operand split of those kernels on its own (the packed weights, once per step; tests): x[n] -> three planes of n
+ * bf16, x == hi + mid + lo exactly */
 int vqa_x3_split(const float* x, void* hi, void* mid, void* lo, int64_t n /* multiple of 4 */, vqa_stream_t stream);
 /* x3-packed activations: a tensor [pixels][C] (C % 4 == 0) split once per tensor instead of by every workgroup that
  * reads it: every four consecutive channels are 24 bytes hi[4] mid[4] lo[4] bf16 (6 bytes per element, same order).

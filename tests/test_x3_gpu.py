@@ -265,3 +265,28 @@ def test_persistent_tiles_equal_one_workgroup_per_tile(knob):
     for a, c in zip(out["default"], out["0"]):
         assert torch.equal(a, c)
     assert torch.equal(out["default"][3], out["default"][4])
+
+
+def test_fp32x3_falls_back_to_fp32_kernels_on_small_layers():
+    """Layers the split kernels do not take (channel counts that are no multiples of 32, narrow rows) keep the fp32 MFMA
+    kernels: on such a model the fp32x3 module is the fp32 module, bit for bit."""
+    from dl_vqa_amd import VqaNet
+    from oracle import vqa_oracle as O
+    cfg = {
+        "text": {"question_features": 32, "embedding_features": 20, "dropout": 0.0, "num_lstm_layers": 1, "bidirectional": True},
+        "image": {"kernel_size": 3, "dropout": 0.0, "num_channels": [3, 8, 16, 24], "stride": 1, "do_skip_connection": False},
+        "attention": {"hidden_dim": 64, "glimpses": 2, "do_option": "+", "dropout": 0.0},
+        "classifier": {"hidden_dim": 40, "dropout": 0.0},
+        "max_answers": 24,
+    }
+    v, q, a_idx, a_val, _, _, ql = O.synthetic_batch(3, 48, 6, 50, 24, seed=2)
+    ys = []
+    for dt in ("fp32", "fp32x3"):
+        torch.manual_seed(4)
+        m = VqaNet(cfg, 50, compute_dtype=dt).to(DEV).eval()
+        y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
+        y.sum().backward()
+        torch.cuda.synchronize()
+        ys.append((y.detach(), [p.grad.clone() for p in m.parameters()]))
+    assert torch.equal(ys[0][0], ys[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(ys[0][1], ys[1][1]))

@@ -38,6 +38,27 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void gemm_x3_kernel(typename AL::P
   gemm_epilogue<Cfg>(pe, acc, m0, n0, wm, wn, lane);
 }
 
+// persistent variant (no split-K): 256 workgroups walk the tiles, the loaders run ahead into the next tile during the
+// epilogue -- with K = 256 (v_conv forward: 8 K-steps per tile) prologue and epilogue are most of a tile's life
+template <class Cfg, class AL, class BL>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void gemm_x3_persistent_kernel(typename AL::Params pa, typename BL::Params pb,
+                                                                             EpiParams pe, int tiles_m, int tiles_n, int nk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  gemm_persistent_x<Cfg, AL, BL>(
+      xcd_swizzle(blockIdx.x, gridDim.x), gridDim.x, tiles_m * tiles_n, nk, smem,
+      [&](int t, AL& al, BL& bl) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        al.init(pa, mt * Cfg::BM, loader_tid<Cfg>(), 0);
+        bl.init(pb, nt * Cfg::BN, loader_tid<Cfg>(), 0);
+      },
+      [&](int t, f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        gemm_epilogue<Cfg>(pe, acc, mt * Cfg::BM, nt * Cfg::BN, wm, wn, lane);
+      });
+}
+
 struct GemmPlanX { int tiles_m, tiles_n, nk, splits, ks_per_split; };
 static GemmPlanX plan_gemm_x3(int M, int N, int K) {
   GemmPlanX p;
@@ -61,6 +82,13 @@ template <class AL, class BL>
 static int launch_gemm_x3(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
                           const GemmPlanX& p, hipStream_t s) {
   using SL = SmemLayoutX<CfgG, AL::kTypeR, BL::kTypeR>;
+  if (p.splits == 1 && p.tiles_m * p.tiles_n > 256 && knobs().persistent != 0) {
+    auto pk = gemm_x3_persistent_kernel<CfgG, AL, BL>;
+    int rc = ensure_dyn_smem(reinterpret_cast<const void*>(pk), SL::BYTES, "hipFuncSetAttribute(gemm_x3_p)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(pk, dim3(256), dim3(CfgG::THREADS), SL::BYTES, s, pa, pb, pe, p.tiles_m, p.tiles_n, p.nk);
+    return check_hip(hipGetLastError(), "gemm_x3_persistent_kernel launch");
+  }
   auto kern = gemm_x3_kernel<CfgG, AL, BL>;
   int rc = ensure_dyn_smem(reinterpret_cast<const void*>(kern), SL::BYTES, "hipFuncSetAttribute(gemm_x3)");
   if (rc) return rc;

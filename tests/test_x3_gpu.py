@@ -191,7 +191,8 @@ def test_fp32x3_module_uses_packed_activations_and_matches_fp32_module():
         assert e < 1e-3, (k, e)
 
 
-@pytest.mark.parametrize("M,N,K", [(1352, 1024, 256), (1024, 256, 5000), (700, 256, 1024), (200, 130, 70)])
+@pytest.mark.parametrize("M,N,K", [(1352, 1024, 256), (1024, 256, 5000), (700, 256, 1024), (200, 130, 70),
+                                   (20000, 520, 96)])     # 105 x 5 tiles: the persistent kernel, tails in M and N
 @pytest.mark.parametrize("transA,transB", [(False, True), (False, False), (True, True), (True, False)])
 def test_gemm_x3_layouts(M, N, K, transA, transB):
     """vqa_gemm_x3 in the four operand layouts (tails in M, N, K; split-K slabs for the few-tile shapes) against

@@ -17,7 +17,16 @@ using CfgXn = TileCfg<256, 64, 4, 1, 4, VQA_X3_PF>;      // 64 output columns (c
 // K-steps of loads in flight per kernel family (same box, packed operands, conv1 / conv2 ms): dgrad 1: 2.75 / 1.83, 2: 2.82 /
 // 1.88, 3 spills (5.7 / 2.4); wgrad 1: 2.05 / 1.85, 2: 1.94 / 1.72, 3: 1.89 / 1.67; forward the same at 1, 2 and 3
 using CfgXd = TileCfg<192, 128, 2, 2, 4, 1>;
+#ifndef VQA_X3_ND16
+#define VQA_X3_ND16 1
+#endif
+#if VQA_X3_ND16
+// 64 output columns (conv1 dgrad): every routed A element feeds only 64 columns, so the loaders are the long pole (MfmaUtil
+// 38 % with 4 + 4 waves).  16 waves: 8 MFMA waves of 64 x 32 (104 VGPRs) + 8 loader waves, four waves per SIMD.
+using CfgXnd = TileCfg<256, 64, 4, 2, 8, 1>;
+#else
 using CfgXnd = TileCfg<256, 64, 4, 1, 4, 1>;
+#endif
 using CfgXw = TileCfg<192, 128, 2, 2, 4, 3>;
 
 // ------------------------------------------------------------------ activations split ahead of time ("x3-packed")
@@ -317,7 +326,7 @@ __device__ __forceinline__ void conv_pool_epilogue_x3p(f32x16 (&acc)[Cfg::TM][Cf
 }
 
 template <class Cfg, class AL, bool OP>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename AL::Params pa,
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::THREADS / 256) void conv_fwd_x3_kernel(typename AL::Params pa,
                                                                       typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
                                                                       const float* __restrict__ bias, void* pooled,
                                                                       uint8_t* amax, int Co, int tiles_m, int tiles_n, int nk) {
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_kernel(typename A
 
 // persistent variants: one workgroup per CU walks the tiles, the loaders run ahead into the next tile during the epilogue
 template <class Cfg, class AL, bool OP>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_persistent_kernel(typename AL::Params pa,
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::THREADS / 256) void conv_fwd_x3_persistent_kernel(typename AL::Params pa,
                                                                                  typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
                                                                                  const float* __restrict__ bias, void* pooled,
                                                                                  uint8_t* amax, int Co, int tiles_m, int tiles_n,
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_fwd_x3_persistent_kernel
 }
 
 template <class Cfg, class AL>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_persistent_kernel(typename AL::Params pa,
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::THREADS / 256) void conv_dgrad_x3_persistent_kernel(typename AL::Params pa,
                                                                                    typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
                                                                                    float* dx, int CiP, int tiles_m, int tiles_n,
                                                                                    int nk) {
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_persistent_kern
 }
 
 template <class Cfg, class AL>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename AL::Params pa,
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::THREADS / 256) void conv_dgrad_x3_kernel(typename AL::Params pa,
                                                                         typename PlainCx<Cfg::NVB, Cfg::LT>::Params pb,
                                                                         float* dx, int CiP, int tiles_m, int tiles_n, int nk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void conv_dgrad_x3_kernel(typename
 }
 
 template <class Cfg, class AL, class BL>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void conv_wgrad_x3_kernel(typename AL::Params pa, typename BL::Params pb,
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::THREADS / 256) void conv_wgrad_x3_kernel(typename AL::Params pa, typename BL::Params pb,
                                                                         float* slab, int tiles_m, int tiles_n, int nk,
                                                                         int ks_per_split) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

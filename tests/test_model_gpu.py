@@ -406,8 +406,10 @@ def test_train_mode_matches_oracle_with_shared_masks(do_option):
         assert e < 2e-4, (k, e)
 
 
-def test_train_mode_full224_matches_oracle_with_shared_masks():
-    """The north-star architecture (224x224, B=2, T=14, A=1000) in train mode, HIP vs oracle with shared masks."""
+@pytest.mark.parametrize("compute_dtype", ["fp32", "fp32x3"])
+def test_train_mode_full224_matches_oracle_with_shared_masks(compute_dtype):
+    """The north-star architecture (224x224, B=2, T=14, A=1000) in train mode, HIP vs oracle with shared masks; the same
+    tolerances for the fp32x3 mode (conv blocks 1-2 and v_conv on the bf16 matrix cores through exact operand splits)."""
     from oracle import vqa_oracle as O
     from dl_vqa_amd.train import soft_ce_loss_and_score
     from tests.hip_masks import hip_masks
@@ -415,7 +417,7 @@ def test_train_mode_full224_matches_oracle_with_shared_masks():
     meta = g.meta
     torch.manual_seed(meta["seed"])
     cfg = full_cfg(meta["A"])
-    m = build(cfg, meta["V"]).train()
+    m = build(cfg, meta["V"], compute_dtype=compute_dtype).train()
     sd = {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}
     v, q, ql, a_idx, a_val, _ = full_inputs(meta)
     y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
@@ -426,12 +428,12 @@ def test_train_mode_full224_matches_oracle_with_shared_masks():
     masks = hip_masks(m._engine, ctx.seed, 2, q.shape[1], ctx.acts[-1].shape[1], DEV)
     y_ref, loss_ref, grads_ref = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks)
     err = float((y.detach().cpu() - y_ref).abs().max())
-    print(f"[parity] train-mode full224 logits max abs err {err:.3e}; loss {float(loss):.6f} vs {float(loss_ref):.6f}")
+    print(f"[parity] train-mode full224 ({compute_dtype}) logits max abs err {err:.3e}; loss {float(loss):.6f} vs {float(loss_ref):.6f}")
     assert err < 1e-3
     assert abs(float(loss) - float(loss_ref)) < 1e-4
     for k, p in m.named_parameters():
         e = grad_err(k, p.grad, grads_ref[k], "+")
-        print(f"[parity] train-mode full224 grad {k}: {e:.3e}")
+        print(f"[parity] train-mode full224 ({compute_dtype}) grad {k}: {e:.3e}")
         assert e < 1e-3, (k, e)        # fp32 both sides, K up to 6.4e5 products per element in the conv wgrads
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""conv1 / conv2 forward, dgrad, wgrad at the headline shape: fp32 MFMA kernels against the 3 x bf16 split kernels
-(HIP events on the launch stream; fp32-equivalent TFLOP/s, % of the fp32 MFMA peak 157.3 and of 2500/6 = 416.7)."""
+"""conv1 / conv2 forward, dgrad, wgrad at the headline shape: fp32 MFMA kernels against the 3 x bf16 split kernels, the
+latter with fp32 operands (split in the loaders) and with x3-packed operands (HIP events on the launch stream;
+fp32-equivalent TFLOP/s, % of the fp32 MFMA peak 157.3 and of 2500/6 = 416.7).  --gemm: the three v_conv products."""
 import argparse
 import os
 import sys
@@ -54,12 +55,11 @@ def main():
                          ("wgrad", lambda x3: ops.conv_wgrad(x, dp, am, dw, db, 1, x3=x3))):
             t = {x3: timeit(lambda: fn(x3), args.iters) for x3 in (False, True)}
             tf = {k: flops / v / 1e9 for k, v in t.items()}
-            if True:
-                fp = {"fwd": lambda: ops.conv_fwd(xp, wfx, b, 1, x3=True),
-                      "wgrad": lambda: ops.conv_wgrad(xp, dp, am, dw, db, 1, x3=True, dpooled_packed=dpp),
-                      "dgrad": lambda: ops.conv_dgrad(dpp, am, wdx, x.shape, 1, out=dx, x3=True)}[name]
-                tp = timeit(fp, args.iters)
-                print(f"conv{l}_{name:6s} packed input: {tp:7.3f} ms {flops / tp / 1e9:6.1f} TF   x{t[False] / tp:.2f}", flush=True)
+            fp = {"fwd": lambda: ops.conv_fwd(xp, wfx, b, 1, x3=True),
+                  "wgrad": lambda: ops.conv_wgrad(xp, dp, am, dw, db, 1, x3=True, dpooled_packed=dpp),
+                  "dgrad": lambda: ops.conv_dgrad(dpp, am, wdx, x.shape, 1, out=dx, x3=True)}[name]
+            tp = timeit(fp, args.iters)     # operands split once per tensor (x3-packed): what the engine runs
+            print(f"conv{l}_{name:6s} packed input: {tp:7.3f} ms {flops / tp / 1e9:6.1f} TF   x{t[False] / tp:.2f}", flush=True)
             print(f"conv{l}_{name:6s} fp32-MFMA {t[False]:7.3f} ms {tf[False]:6.1f} TF ({100 * tf[False] / 157.3:4.1f}%)   "
                   f"3xbf16 {t[True]:7.3f} ms {tf[True]:6.1f} TF ({100 * tf[True] / 416.7:4.1f}% of 416.7)   x{t[False] / t[True]:.2f}",
                   flush=True)

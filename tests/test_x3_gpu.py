@@ -291,3 +291,35 @@ def test_fp32x3_falls_back_to_fp32_kernels_on_small_layers():
         ys.append((y.detach(), [p.grad.clone() for p in m.parameters()]))
     assert torch.equal(ys[0][0], ys[1][0])
     assert all(torch.equal(a, b) for a, b in zip(ys[0][1], ys[1][1]))
+
+
+def test_batch_chunking_with_packed_operands(knob):
+    """Batches whose tensors would pass 4 GiB are walked in chunks inside the C ABI; VQA_CONV_CHUNK forces that path on
+    small tensors.  With x3-packed inputs / outputs / pooled gradients the chunk offsets count 6 bytes per element:
+    forward (both output forms) and dgrad are bit-identical to one launch, wgrad's chunks are extra split-K slabs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(78)
+    B, H, W, Ci, Co = 5, 38, 42, 64, 128
+    x = torch.randn(B, H, W, Ci, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).to(DEV)
+    b = (torch.randn(Co, generator=g) * 0.1).to(DEV)
+    wf, wd = ops.conv_pack_weights(w, Ci)
+    wfx, wdx, xp = ops.x3_split(wf), ops.x3_split(wd), ops.x3_pack(x)
+
+    def run():
+        pooled, am = ops.conv_fwd(xp, wfx, b, 1, x3=True)
+        pooled_p, _ = ops.conv_fwd(xp, wfx, b, 1, x3=True, out_packed=True)
+        dp = torch.sin(pooled * 3.0) + 0.1
+        dpp = ops.x3_pack(dp)
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        ops.conv_wgrad(xp, dp, am, dw, db, 1, x3=True, dpooled_packed=dpp)
+        dx = ops.conv_dgrad(dpp, am, wdx, x.shape, 1, x3=True)
+        torch.cuda.synchronize()
+        return pooled, am, pooled_p, dx, dw, db
+
+    ref = run()
+    knob("VQA_CONV_CHUNK", "2")      # 2 + 2 + 1 images
+    got = run()
+    for k in range(4):
+        assert torch.equal(ref[k], got[k]), k
+    assert rel_err(got[4], ref[4]) < 1e-5 and rel_err(got[5], ref[5]) < 1e-5

@@ -40,6 +40,8 @@ PROTOTYPES = {
     "vqa_conv3x3_x3_supported": (i32, [i32, i32, i32, i32, i32]),
     "vqa_x3_split": (i32, [f32p, vp, vp, vp, i64, vp]),
     "vqa_x3_pack": (i32, [f32p, vp, i64, vp]),
+    "vqa_x3_pack_pooled_grad_workspace_bytes": (i64, [i32]),
+    "vqa_x3_pack_pooled_grad": (i32, [f32p, u8p, vp, f32p, i64, i32, f32p, i64, vp]),
     "vqa_conv3x3_relu_pool_fwd_x3": (i32, [vp, i32, vp, f32p, vp, i32, u8p, i32, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_conv3x3_dgrad_x3": (i32, [vp, i32, u8p, vp, f32p, i32, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_conv3x3_wgrad_x3_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),

@@ -511,19 +511,29 @@ static WgradPlanX plan_wgrad_x3(const ConvGeom& g) {
 // window sit side by side, 256 / (Co/4) window lanes per block combine through LDS in a fixed order; the blocks write
 // part rows that wgrad_bias_reduce_kernel adds up.  Co % 4 == 0, Co <= 1024.  (The split kernels' B fragments are bf16
 // planes: summing them in the MFMA waves as conv.hip does would cost more than this pass over 0.1-0.4 GB.)
-constexpr int kBiasParts = 1024;
+// PACK: the same pass also writes the gradient in the x3-packed form (vqa_x3_pack_pooled_grad: one read of dP serves the
+// bias gradient and the split).
+constexpr int kBiasParts = 512;
+template <bool PACK>
 __global__ __launch_bounds__(256) void conv_bias_grad_kernel(const float* dp, const uint8_t* am, float* part,
-                                                             int64_t windows, int Co, int64_t per) {
+                                                             int64_t windows, int Co, int64_t per, uint2* packed) {
   extern __shared__ __attribute__((aligned(16))) float red[];      // [window lanes][Co]
   const int cpr = Co / 4, nwl = 256 / cpr;
   const int c = threadIdx.x % cpr, wl = threadIdx.x / cpr;
   const int64_t w0 = (int64_t)blockIdx.x * per;
   const int64_t w1 = w0 + per < windows ? w0 + per : windows;
   float4 acc = f4zero();
+  const SplitConsts kc = split_consts();
   if (wl < nwl) {
     for (int64_t w = w0 + wl; w < w1; w += nwl) {
       const float4 d = *reinterpret_cast<const float4*>(dp + w * Co + 4 * c);
       const uint32_t a = *reinterpret_cast<const uint32_t*>(am + w * Co + 4 * c);
+      if (PACK) {
+        uint2 h, m, l;
+        split4(d, h, m, l, kc);
+        uint2* o = packed + 3 * (w * cpr + c);
+        o[0] = h; o[1] = m; o[2] = l;
+      }
       acc.x += (a & 0xffu) != 4u ? d.x : 0.f;
       acc.y += ((a >> 8) & 0xffu) != 4u ? d.y : 0.f;
       acc.z += ((a >> 16) & 0xffu) != 4u ? d.z : 0.f;
@@ -554,6 +564,24 @@ __global__ void x3_pack_kernel(const float4* x, uint2* out, int64_t n4) {
   out[3 * i] = h; out[3 * i + 1] = m; out[3 * i + 2] = l;
 }
 
+// bias gradient (+ optional packed copy) of a pooled gradient [rows][Co]; `parts` = kBiasParts * Co floats of workspace
+static int launch_bias_grad(const float* dp, const uint8_t* am, float* dbias, void* packed, int64_t rows, int Co, float* parts,
+                            hipStream_t s) {
+  const int nparts = rows < kBiasParts ? (int)rows : kBiasParts;
+  const int64_t per = (rows + nparts - 1) / nparts;
+  const size_t lds = (size_t)(256 / (Co / 4)) * Co * 4;
+  if (packed)
+    hipLaunchKernelGGL(conv_bias_grad_kernel<true>, dim3(nparts), dim3(256), lds, s, dp, am, parts, rows, Co, per,
+                       static_cast<uint2*>(packed));
+  else
+    hipLaunchKernelGGL(conv_bias_grad_kernel<false>, dim3(nparts), dim3(256), lds, s, dp, am, parts, rows, Co, per,
+                       (uint2*)nullptr);
+  int rc = check_hip(hipGetLastError(), "conv_bias_grad launch");
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, parts, dbias, nparts, Co);
+  return check_hip(hipGetLastError(), "wgrad_bias_reduce launch");
+}
+
 static bool x3_conv_ok(int CiP, int Co, int Wp) { return CiP % BK == 0 && Co % BK == 0 && 2 * Wp >= BK; }
 // images per launch: as batch_chunk, with the tensors at 6 bytes per element (the packed forms; also used for fp32
 // tensors so that the forward / dgrad / wgrad / workspace computations agree whatever the form)
@@ -580,6 +608,16 @@ int vqa_x3_pack(const float* x, void* out, int64_t n, vqa_stream_t stream) {
   hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(x), static_cast<uint2*>(out), n / 4);
   return check_hip(hipGetLastError(), "x3_pack launch");
+}
+
+int64_t vqa_x3_pack_pooled_grad_workspace_bytes(int Co) { return (int64_t)kBiasParts * Co * 4; }
+
+int vqa_x3_pack_pooled_grad(const float* dpooled, const uint8_t* argmax, void* packed, float* dbias, int64_t windows, int Co,
+                            float* workspace, int64_t workspace_bytes, vqa_stream_t stream) {
+  VQA_REQUIRE(dpooled && argmax && packed && dbias && workspace && windows > 0, "vqa_x3_pack_pooled_grad: null pointer");
+  VQA_REQUIRE(Co % 4 == 0 && Co > 0 && Co <= 1024, "vqa_x3_pack_pooled_grad: Co=%d (multiple of 4, <= 1024)", Co);
+  VQA_REQUIRE(workspace_bytes >= vqa_x3_pack_pooled_grad_workspace_bytes(Co), "vqa_x3_pack_pooled_grad: workspace too small");
+  return launch_bias_grad(dpooled, argmax, dbias, packed, windows, Co, workspace, (hipStream_t)stream);
 }
 
 int vqa_conv3x3_x3_supported(int H, int W, int CiP, int Co, int stride) {
@@ -667,7 +705,7 @@ int64_t vqa_conv3x3_wgrad_x3_workspace_bytes(int B, int H, int W, int CiP, int C
 int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, const void* dpooled_packed,
                          const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W, int CiP, int Ci, int Co,
                          int stride, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream) {
-  VQA_REQUIRE(x && dpooled && argmax && dw && dbias && workspace && B > 0, "vqa_conv3x3_wgrad_x3: null pointer");
+  VQA_REQUIRE(x && dpooled && argmax && dw && workspace && B > 0, "vqa_conv3x3_wgrad_x3: null pointer");
   VQA_REQUIRE(Ci >= 1 && Ci <= CiP && Co <= 1024, "vqa_conv3x3_wgrad_x3: Ci=%d CiP=%d Co=%d (Co <= 1024)", Ci, CiP, Co);
   const ConvGeom g1 = make_geom(1, H, W, CiP, Co, stride);
   VQA_REQUIRE(g1.Hp > 0 && g1.Wp > 0 && x3_conv_ok(CiP, Co, g1.Wp),
@@ -730,16 +768,10 @@ int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, cons
                      Co);
   rc = check_hip(hipGetLastError(), "wgrad_reduce launch");
   if (rc) return rc;
-  // bias gradient = sum of the pooled gradient over the windows whose ReLU was alive (arg-max byte != 4)
-  const int64_t rows = (int64_t)B * g1.Hp * g1.Wp;
-  const int nparts = rows < kBiasParts ? (int)rows : kBiasParts;
-  const int64_t per = (rows + nparts - 1) / nparts;
-  hipLaunchKernelGGL(conv_bias_grad_kernel, dim3(nparts), dim3(256), (size_t)(256 / (Co / 4)) * Co * 4, s, dpooled, argmax,
-                     bias_parts, rows, Co, per);
-  rc = check_hip(hipGetLastError(), "conv_bias_grad launch");
-  if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bias_parts, dbias, nparts, Co);
-  return check_hip(hipGetLastError(), "wgrad_bias_reduce launch");
+  // bias gradient = sum of the pooled gradient over the windows whose ReLU was alive (arg-max byte != 4); dbias == NULL:
+  // the caller already has it (vqa_x3_pack_pooled_grad)
+  if (!dbias) return VQA_OK;
+  return launch_bias_grad(dpooled, argmax, dbias, nullptr, (int64_t)B * g1.Hp * g1.Wp, Co, bias_parts, s);
 }
 
 }  // extern "C"

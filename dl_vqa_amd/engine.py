@@ -503,9 +503,10 @@ class Engine:
             x_shape = ops.nhwc_shape(ctx.acts[l])
             x3 = self._x3_layer(x_shape, dP.shape[3])
             # fp32x3: the pooled gradient is split once (x3-packed) for its two readers, wgrad and dgrad
-            dPp = ops.x3_pack(dP) if x3 else None
-            ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
-                           self.stride, tag=l, x3=x3, dpooled_packed=dPp)
+            # (one pass: it also sums the bias gradient)
+            dPp = ops.x3_pack_pooled_grad(dP, ctx.idxs[l], Gr[f"image.conv{l}.bias"]) if x3 else None
+            ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"],
+                           None if x3 else Gr[f"image.conv{l}.bias"], self.stride, tag=l, x3=x3, dpooled_packed=dPp)
             if l > 0:
                 dP = ops.conv_dgrad(dPp if x3 else dP, ctx.idxs[l], ctx.wds[l], x_shape, self.stride, tag=l, x3=x3)
         ready("image")

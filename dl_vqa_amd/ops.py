@@ -91,6 +91,16 @@ def nhwc_shape(x) -> tuple:
     return tuple(x.shape)
 
 
+def x3_pack_pooled_grad(dpooled: torch.Tensor, amax: torch.Tensor, dbias: torch.Tensor) -> torch.Tensor:
+    """x3_pack(dpooled) and, from the same read, dbias = sum of dpooled over the windows whose ReLU was alive."""
+    Co = dpooled.shape[-1]
+    out = torch.empty(tuple(dpooled.shape[:-1]) + (Co // 4, 3, 4), dtype=torch.bfloat16, device=dpooled.device)
+    ws = workspace(_lib.load().vqa_x3_pack_pooled_grad_workspace_bytes(Co), dpooled.device)
+    call("vqa_x3_pack_pooled_grad", ptr(dpooled), ptr(amax), ptr(out), ptr(dbias), dpooled.numel() // Co, Co, ptr(ws),
+         ws.numel() * 4, stream())
+    return out
+
+
 def _x3_input(x):
     """(B, H, W, CiP, packed) of a conv input that is fp32 NHWC or x3-packed."""
     if x.dtype == torch.bfloat16 and x.dim() == 6:
@@ -140,7 +150,8 @@ def conv_dgrad(dpooled, amax, wd, x_shape, stride: int = 1, tag: int = 0, out=No
 
 def conv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, stride: int = 1, tag: int = 0, x3: bool = False,
                dpooled_packed=None):
-    """x3: x may be x3-packed; dpooled_packed (optional) = x3_pack(dpooled), read by the contraction instead of dpooled."""
+    """x3: x may be x3-packed; dpooled_packed (optional) = x3_pack(dpooled), read by the contraction instead of dpooled;
+    dbias None (x3 only): the bias gradient is not computed here (x3_pack_pooled_grad already produced it)."""
     lib = _lib.load()
     B, H, W, CiP, packed = _x3_input(x) if x3 else (*x.shape, 0)
     Co, Ci = dw.shape[0], dw.shape[1]

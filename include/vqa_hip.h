@@ -328,8 +328,13 @@ int vqa_conv3x3_relu_pool_fwd_x3(const void* x, int x_packed, const void* wf_pla
 int vqa_conv3x3_dgrad_x3(const void* dpooled, int dp_packed, const uint8_t* argmax, const void* wd_planes, float* dx, int B,
                          int H, int W, int CiP, int Co, int stride, int tag, vqa_stream_t stream);
 int64_t vqa_conv3x3_wgrad_x3_workspace_bytes(int B, int H, int W, int CiP, int Co, int stride);
-/* dpooled (fp32) always: the bias gradient is summed from it; dpooled_packed (optional): the same gradient x3-packed,
- * read by the contraction instead */
+/* One pass over a pooled gradient [windows][Co] for its two needs in the fp32x3 backward: the x3-packed copy (read by
+ * dgrad and wgrad) and the bias gradient (sum over the windows whose ReLU was alive, arg-max byte != 4). */
+int64_t vqa_x3_pack_pooled_grad_workspace_bytes(int Co);
+int vqa_x3_pack_pooled_grad(const float* dpooled, const uint8_t* argmax, void* packed, float* dbias, int64_t windows, int Co,
+                            float* workspace, int64_t workspace_bytes, vqa_stream_t stream);
+/* dpooled (fp32): the bias gradient is summed from it unless dbias is NULL (the caller has it from
+ * vqa_x3_pack_pooled_grad); dpooled_packed (optional): the same gradient x3-packed, read by the contraction instead */
 int vqa_conv3x3_wgrad_x3(const void* x, int x_packed, const float* dpooled, const void* dpooled_packed,
                          const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W, int CiP, int Ci, int Co,
                          int stride, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);

@@ -105,6 +105,12 @@ def test_conv_x3_matches_float64_like_native_fp32(B, H, W, Ci, Co, stride):
             assert torch.equal(dw_p, dw) and torch.equal(db_p, db)
             # x3-packed pooled gradient (routing as a mask on the packed halves): bit-identical again
             dyp = ops.x3_pack(dyd)
+            db_s = torch.empty_like(db)
+            assert torch.equal(ops.x3_pack_pooled_grad(dyd, am, db_s), dyp)        # pack + bias gradient in one pass
+            dw_s = torch.empty_like(dw)
+            ops.conv_wgrad(xp, dyd, am, dw_s, None, stride, x3=True, dpooled_packed=dyp)   # dbias None: not recomputed
+            torch.cuda.synchronize()
+            assert torch.equal(db_s, db) and torch.equal(dw_s, dw)
             dx_p = ops.conv_dgrad(dyp, am, wdx, xd.shape, stride, x3=True)
             dw_q, db_q = torch.empty_like(dw), torch.empty_like(db)
             ops.conv_wgrad(xp, dyd, am, dw_q, db_q, stride, x3=True, dpooled_packed=dyp)

@@ -9,7 +9,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvqa_hip.so")
-SOURCES = ["gemm.hip", "conv.hip", "conv0.hip", "lstm.hip", "elementwise.hip", "bf16.hip", "conv_bf16.hip", "conv_x3.hip", "gemm_x3.hip"]
+# a source, or (source, object suffix, extra flags): gemm.hip and gemm_x3.hip are compiled in parts (host side + kernels by tile
+# shape / operand layout: the fused epilogue's straight-line variants compile slowly), the slowest units first
+SOURCES = ([("gemm.hip", f"_p{k}", [f"-DVQA_GEMM_PART={k}"]) for k in (2, 3, 4, 5)]
+           + [("gemm_x3.hip", f"_p{k}", [f"-DVQA_GEMM_PART={k}"]) for k in (1, 2, 3, 4)]
+           + ["bf16.hip", ("gemm.hip", "_p1", ["-DVQA_GEMM_PART=1"]), "conv.hip", "conv_x3.hip", "conv_bf16.hip", "gemm.hip",
+              "gemm_x3.hip", "conv0.hip", "lstm.hip", "elementwise.hip"])
 HEADERS = ["common.hpp", "gemm_core.hpp", "gemm_epilogue.hpp", "bf16_core.hpp", "x3_core.hpp", "conv_device.inc", "conv_host.inc", "conv_bf16.inc", os.path.join("..", "..", "include", "vqa_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
@@ -36,12 +41,13 @@ def build_library(force: bool = False, verbose: bool = True, diag: bool = False)
     jobs = []
     lib = LIB.replace(".so", "_diag.so") if diag else LIB
     flags = FLAGS + (["-DVQA_DIAG"] if diag else [])
-    for src in SOURCES:
+    for entry in SOURCES:
+        src, suffix, extra = entry if isinstance(entry, tuple) else (entry, "", [])
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", "_diag.o" if diag else ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", suffix + ("_diag.o" if diag else ".o")))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([_hipcc()] + flags + ["-c", s, "-o", o])
+            jobs.append([_hipcc()] + flags + extra + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -51,7 +57,7 @@ def build_library(force: bool = False, verbose: bool = True, diag: bool = False)
             raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
         return r
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)

@@ -10,8 +10,16 @@
 #include "gemm_core.hpp"
 #include "gemm_epilogue.hpp"
 
+// This file is compiled six times (dl_vqa_amd/build.py): VQA_GEMM_PART = 0 is the host plumbing + the C ABI, parts 1-5 hold
+// the kernels (1: 64x64 tiles; 2, 3: 128x128 tiles with A stored [M][K] / [K][M]; 4, 5: the same for 256x128) -- the fused
+// epilogue's straight-line variants make a single translation unit with all of them take seven minutes to compile.
+#ifndef VQA_GEMM_PART
+#define VQA_GEMM_PART 0
+#endif
+
 namespace vqa {
 
+#if VQA_GEMM_PART == 0
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -92,6 +100,8 @@ ProfScope::~ProfScope() {
   hipEventRecord(g_prof_ev.back().second, s);
 }
 
+#endif  // VQA_GEMM_PART == 0
+
 // Persistent variant (no split-K, single Raw set): min(tiles, resident slots) workgroups walk the tiles.
 template <class Cfg, class AL, class BL>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_persistent_kernel(
@@ -151,6 +161,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_kernel(type
 }
 
 // ------------------------------------------------------------------ host side
+#if VQA_GEMM_PART == 0
 GemmPlan plan_gemm(int M, int N, int K, int bk) {
   GemmPlan p;
   const int nk = (K + bk - 1) / bk;
@@ -195,8 +206,10 @@ GemmPlan plan_gemm(int M, int N, int K, int bk) {
   return p;
 }
 
+#endif  // VQA_GEMM_PART == 0
+
 template <class Cfg, class AL, class BL>
-static int launch_gemm(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
+int launch_gemm(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
                        const GemmPlan& p, int K, hipStream_t s) {
   using SL = SmemLayout<Cfg, AL::kTypeR, BL::kTypeR>;
   if constexpr (Cfg::BM * Cfg::BN > 64 * 64) {
@@ -233,8 +246,8 @@ using Cfg256 = TileCfg<256, 128, 4, 2>;
 using Cfg64 = TileCfg<64, 64, 2, 2>;
 
 template <class Cfg>
-static int dispatch_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
-                         const EpiParams& pe, const GemmPlan& p, int M, int N, int K, hipStream_t s) {
+int dispatch_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
+                  const EpiParams& pe, const GemmPlan& p, int M, int N, int K, hipStream_t s) {
   using AR = PlainR<Cfg::NVA, Cfg::LT>; using AC = PlainC<Cfg::NVA, Cfg::LT>;
   using BR = PlainR<Cfg::NVB, Cfg::LT>; using BC = PlainC<Cfg::NVB, Cfg::LT>;
   if (!transA && transB) return launch_gemm<Cfg, AR, BR>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
@@ -243,8 +256,34 @@ static int dispatch_gemm(const float* A, int64_t lda, int transA, const float* B
   return launch_gemm<Cfg, AC, BC>({A, lda, M, K}, {B, ldb, N, K}, pe, p, K, s);
 }
 
+// the kernels of launch_gemm<Cfg, A loader, B loader> live in the part that owns the combination
+#define VQA_GEMM_LAUNCH(KW, CFG, AL, BL)                                                                           \
+  KW template int launch_gemm<CFG, AL<CFG::NVA, CFG::LT>, BL<CFG::NVB, CFG::LT>>(                                   \
+      const typename AL<CFG::NVA, CFG::LT>::Params&, const typename BL<CFG::NVB, CFG::LT>::Params&, const EpiParams&, \
+      const GemmPlan&, int, hipStream_t);
+#define VQA_GEMM_OWN(PART, CFG, AL, BL) VQA_GEMM_LAUNCH(, CFG, AL, BL)
+#define VQA_GEMM_EXT(PART, CFG, AL, BL) VQA_GEMM_LAUNCH(extern, CFG, AL, BL)
+#define VQA_GEMM_COMBOS(X1, X2, X3, X4, X5)                                                                        \
+  X1(1, Cfg64, PlainR, PlainR) X1(1, Cfg64, PlainR, PlainC) X1(1, Cfg64, PlainC, PlainR) X1(1, Cfg64, PlainC, PlainC)  \
+  X2(2, Cfg128, PlainR, PlainR) X2(2, Cfg128, PlainR, PlainC) X3(3, Cfg128, PlainC, PlainR) X3(3, Cfg128, PlainC, PlainC) \
+  X4(4, Cfg256, PlainR, PlainR) X4(4, Cfg256, PlainR, PlainC) X5(5, Cfg256, PlainC, PlainR) X5(5, Cfg256, PlainC, PlainC)
+#if VQA_GEMM_PART == 1
+VQA_GEMM_COMBOS(VQA_GEMM_OWN, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT)
+#elif VQA_GEMM_PART == 2
+VQA_GEMM_COMBOS(VQA_GEMM_EXT, VQA_GEMM_OWN, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT)
+#elif VQA_GEMM_PART == 3
+VQA_GEMM_COMBOS(VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_OWN, VQA_GEMM_EXT, VQA_GEMM_EXT)
+#elif VQA_GEMM_PART == 4
+VQA_GEMM_COMBOS(VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_OWN, VQA_GEMM_EXT)
+#elif VQA_GEMM_PART == 5
+VQA_GEMM_COMBOS(VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_OWN)
+#else
+VQA_GEMM_COMBOS(VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT)
+#endif
+
 }  // namespace vqa
 
+#if VQA_GEMM_PART == 0
 using namespace vqa;
 
 extern "C" {
@@ -355,3 +394,4 @@ int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ld
 }
 
 }  // extern "C"
+#endif  // VQA_GEMM_PART == 0

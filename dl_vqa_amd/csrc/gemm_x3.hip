@@ -4,6 +4,12 @@
 #include "x3_core.hpp"
 #include "gemm_epilogue.hpp"
 
+// Compiled five times (dl_vqa_amd/build.py): VQA_GEMM_PART = 0 is the host side + the C ABI, parts 1-4 hold the kernels of
+// one operand layout each (the fused epilogue's straight-line variants are slow to compile).
+#ifndef VQA_GEMM_PART
+#define VQA_GEMM_PART 0
+#endif
+
 namespace vqa {
 
 #ifndef VQA_X3_PF
@@ -79,7 +85,7 @@ static GemmPlanX plan_gemm_x3(int M, int N, int K) {
 }
 
 template <class AL, class BL>
-static int launch_gemm_x3(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
+int launch_gemm_x3(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
                           const GemmPlanX& p, hipStream_t s) {
   using SL = SmemLayoutX<CfgG, AL::kTypeR, BL::kTypeR>;
   if (p.splits == 1 && p.tiles_m * p.tiles_n > 256 && knobs().persistent != 0) {
@@ -97,8 +103,34 @@ static int launch_gemm_x3(const typename AL::Params& pa, const typename BL::Para
   return check_hip(hipGetLastError(), "gemm_x3_kernel launch");
 }
 
+#define VQA_GX3_LAUNCH(KW, AL, BL)                                                                                 \
+  KW template int launch_gemm_x3<AL<CfgG::NVA, CfgG::LT>, BL<CfgG::NVB, CfgG::LT>>(                                  \
+      const typename AL<CfgG::NVA, CfgG::LT>::Params&, const typename BL<CfgG::NVB, CfgG::LT>::Params&, const EpiParams&, \
+      const GemmPlanX&, hipStream_t);
+#if VQA_GEMM_PART == 1
+VQA_GX3_LAUNCH(, PlainR, PlainR)
+#else
+VQA_GX3_LAUNCH(extern, PlainR, PlainR)
+#endif
+#if VQA_GEMM_PART == 2
+VQA_GX3_LAUNCH(, PlainR, PlainC)
+#else
+VQA_GX3_LAUNCH(extern, PlainR, PlainC)
+#endif
+#if VQA_GEMM_PART == 3
+VQA_GX3_LAUNCH(, PlainC, PlainR)
+#else
+VQA_GX3_LAUNCH(extern, PlainC, PlainR)
+#endif
+#if VQA_GEMM_PART == 4
+VQA_GX3_LAUNCH(, PlainC, PlainC)
+#else
+VQA_GX3_LAUNCH(extern, PlainC, PlainC)
+#endif
+
 }  // namespace vqa
 
+#if VQA_GEMM_PART == 0
 using namespace vqa;
 
 extern "C" {
@@ -147,3 +179,4 @@ int vqa_gemm_x3(const float* A, int64_t lda, int transA, const float* B, int64_t
 }
 
 }  // extern "C"
+#endif  // VQA_GEMM_PART == 0

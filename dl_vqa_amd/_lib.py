@@ -8,6 +8,19 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB", os.path.join(_HERE, "libvqa_hip.so"))   # VQA_LIB: diagnostic builds only
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vqa_hip.h")
+
+
+def header_abi_version() -> int:
+    """VQA_ABI_VERSION as include/vqa_hip.h states it: the one number the loader, the tests and build() compare
+    the library's answer with (a stale build_var/*.so or a round-old library then fails here, not in a kernel)."""
+    import re
+    with open(HEADER_PATH) as f:
+        m = re.search(r"^#define\s+VQA_ABI_VERSION\s+(\d+)", f.read(), flags=re.M)
+    if not m:
+        raise VqaHipError(f"{HEADER_PATH}: no VQA_ABI_VERSION")
+    return int(m.group(1))
+
 
 f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 u8p = C.c_void_p
@@ -125,8 +138,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.vqa_abi_version() != 1:
-        raise VqaHipError("libvqa_hip.so ABI version mismatch")
+    want = header_abi_version()
+    if lib.vqa_abi_version() != want:
+        raise VqaHipError(f"{LIB_PATH}: ABI version {lib.vqa_abi_version()}, include/vqa_hip.h says {want} "
+                          "(stale library: rebuild with `python -m dl_vqa_amd.build`)")
     _lib = lib
     return lib
 

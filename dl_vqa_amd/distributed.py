@@ -29,6 +29,7 @@ class DataParallel:
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self._handles: List = []
+        self.issued: List[str] = []             # groups whose collective has been issued, in order (tests, bench)
         model._grad_sync = self
         model._seed_rank = self.rank            # different dropout masks per rank
         if broadcast:
@@ -36,10 +37,17 @@ class DataParallel:
             dist.broadcast(flat_p, src=0, group=process_group)
 
     # called by the backward schedule after the kernels of `group` have been enqueued
-    def bucket_ready(self, model, group: str) -> None:
-        _, flat_g, _ = model.flat_buffers()
+    def bucket_ready(self, model, group: str, flat: Optional[torch.Tensor] = None) -> None:
+        """Start the SUM all-reduce of one group's contiguous range of `flat` (default: the model's own flat
+        gradient buffer).  Every backward of every rank issues exactly these len(GROUPS) collectives, in GROUPS
+        order, over the same ranges -- whichever buffer this rank's backward wrote into (its own flat buffer, or a
+        fresh one under gradient accumulation / a second pending forward): the collective sequence does not depend
+        on rank-local state, so ranks that disagree about that state cannot deadlock or mix up buckets."""
+        if flat is None:
+            _, flat, _ = model.flat_buffers()
         lo, hi = model.group_range(group)
-        self._handles.append(dist.all_reduce(flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self.issued.append(group)
 
     def finish(self, model) -> None:
         for h in self._handles:
@@ -47,11 +55,12 @@ class DataParallel:
         self._handles = []
 
     def reduce_flat(self, flat: torch.Tensor) -> None:
-        """SUM all-reduce of a whole gradient buffer in one piece: the path backward takes when it could not
-        write into the model's own flat buffer (gradient accumulation, several forwards per backward), where
-        the per-bucket overlap does not apply.  Every micro-step's contribution is reduced on its own, so the
-        accumulated p.grad is the reduced sum."""
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+        """SUM all-reduce of a whole gradient buffer laid out like the model's flat buffer, as the same
+        len(GROUPS) bucket collectives in the same order that bucket_ready issues from inside backward (for callers
+        that produced gradients outside the backward schedule)."""
+        for group in GROUPS:
+            self.bucket_ready(self.model, group, flat)
+        self.finish(self.model)
 
     def __call__(self, *args, **kwargs):
         return self.model(*args, **kwargs)

@@ -13,6 +13,7 @@ gradients) so that the optimiser and the data-parallel all-reduce work on contig
 """
 from __future__ import annotations
 
+import warnings
 import weakref
 from collections import OrderedDict
 from typing import Dict, List, Optional
@@ -106,7 +107,8 @@ class _VqaFunction(torch.autograd.Function):
     two aliases of the same memory).  In every other case (gradient accumulation,
     ``zero_grad(set_to_none=False)``, several forwards per backward) the gradients go to a fresh
     buffer that autograd accumulates as usual; under data parallelism that buffer is all-reduced
-    before it is handed to autograd, so replicas never step on unreduced gradients.
+    (through the same four bucket collectives, issued from inside backward in the same order) before it is handed
+    to autograd, so replicas never step on unreduced gradients and the collective sequence is rank-invariant.
     """
 
     @staticmethod
@@ -129,15 +131,22 @@ class _VqaFunction(torch.autograd.Function):
         names = model._names
         others = [c for c in model._pending if c is not ctx]
         direct = not others and all(p.grad is None for p in model._params)
+        if not direct and others and not model._warned_stale:
+            model._warned_stale = True
+            warnings.warn("dl_vqa_amd.VqaNet: backward runs while another grad-enabled forward of this module is still "
+                          "waiting for its backward (an output kept for metrics / logging?): gradients go to a fresh "
+                          "buffer instead of the model's flat gradient buffer (one extra buffer and, for FusedAdam, one "
+                          "copy per step).  Use .detach() or torch.no_grad() for forwards that are never differentiated.")
         flat, Gr = model._grad_buffer(fresh=not direct)
         sync = model._grad_sync
-        on_ready = (lambda group: sync.bucket_ready(model, group)) if (sync is not None and direct) else None
+        # data parallel: the SAME four bucket all-reduces, in the same order, from inside backward on either path
+        # (a rank on the fresh-buffer path used to issue one whole-buffer collective against the other
+        # ranks' four)
+        on_ready = (lambda group: sync.bucket_ready(model, group, flat)) if sync is not None else None
+        model._last_backward_direct = direct
         model._engine.backward(model._param_dict(), ctx.saved, dlogits, Gr, on_ready)
         if sync is not None:
-            if direct:
-                sync.finish(model)
-            else:
-                sync.reduce_flat(flat)
+            sync.finish(model)
         ctx.saved = None
         model._pending.discard(ctx)
         return (None, None, None, None, None) + tuple(Gr[n] for n in names)
@@ -182,6 +191,8 @@ class VqaNet(nn.Module):
         self._last_ctx = None
         self._seed_rank = 0
         self._pending = weakref.WeakSet()   # autograd nodes of forwards whose backward has not run yet
+        self._warned_stale = False
+        self._last_backward_direct = None   # did the last backward write the model's own flat buffer (bench, tests)
         self._bad_tokens = None             # device counter of out-of-vocabulary token ids (+ pinned host copy, event)
         self._bad_host = None
         self._bad_event = None

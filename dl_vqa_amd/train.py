@@ -66,9 +66,19 @@ def batch_accuracy(predicted, true):
 
 def run_batch(model, log_softmax, batch_data, max_answers, batch_divisor: Optional[int] = None):
     """Reference signature (train.py:172-208). `log_softmax` is accepted and unused: the fused loss
-    kernel computes log-softmax, the sparse soft-target cross entropy and the score in one pass."""
+    kernel computes log-softmax, the sparse soft-target cross entropy and the score in one pass.
+
+    The loss is divided by the batch (train.py:206).  Under data parallelism (the model carries a
+    dl_vqa_amd.distributed.DataParallel synchroniser) the divisor defaults to the GLOBAL batch, local batch x
+    world size, because the gradients are SUM-all-reduced: the reference's own loop, which calls
+    run_batch(model, log_softmax, batch_data, max_answers) with no divisor (train.py:70-73), then trains on the
+    mean over the global batch exactly as it does on one GPU."""
     v, q, a_indices, a_values, a_length, idx, q_len = batch_data
     dev = next(model.parameters()).device
+    if batch_divisor is None:
+        sync = getattr(model, "_grad_sync", None)
+        if sync is not None:
+            batch_divisor = int(v.shape[0]) * int(sync.world_size)
     v = v.to(dev, non_blocking=True)
     q = q.to(dev, non_blocking=True)
     a_indices = a_indices.to(dev, non_blocking=True)
@@ -111,34 +121,56 @@ class FusedAdam:
         return flat_p, flat_g
 
     def zero_grad(self, set_to_none: bool = True):
-        """Always drops the gradients (set_to_none=False is accepted and treated the same): backward then
-        writes the next gradients straight into the flat buffer instead of accumulating."""
+        """torch.optim.Optimizer.zero_grad semantics.  set_to_none=True (torch's default) drops the gradients:
+        the next backward then writes straight into the flat buffer (the fast path, and the one whose bucket
+        all-reduces see the model's own buffer).  set_to_none=False zeroes existing gradients in place, as torch
+        does; the next backward then goes through a fresh buffer that autograd ADDS to them (correct, one extra
+        buffer pass per step)."""
         for p in self.model.parameters():
-            p.grad = None
+            if set_to_none or p.grad is None:
+                p.grad = None
+            else:
+                p.grad.detach_()
+                p.grad.requires_grad_(False)
+                p.grad.zero_()
 
     def _gather_grads(self, flat_g):
         """The kernel reads the model's flat gradient buffer.  After a plain backward every p.grad IS a view
         of it; after gradient accumulation (or anything else that made autograd allocate its own p.grad) the
-        gradients are copied into their slots first."""
+        gradients are copied into their slots first.  Returns the names of parameters WITHOUT a gradient (frozen
+        with requires_grad=False, or unused): torch.optim.Adam skips those (train.py:55,80), so step() leaves their
+        values and moments untouched."""
         _, _, offsets = self.model.flat_buffers()
         named = list(self.model.named_parameters())
         missing = [n for n, p in named if p.grad is None]
-        if missing:
-            raise RuntimeError(f"FusedAdam.step: parameters without a gradient ({missing[:3]}...): run backward first "
-                               "(torch.optim.Adam would skip them; the fused kernel updates the whole buffer)")
+        if len(missing) == len(named):
+            raise RuntimeError("FusedAdam.step: no parameter has a gradient: run backward first")
         base = flat_g.data_ptr()
         for n, p in named:
             o, k = offsets[n]
-            if p.grad.data_ptr() != base + 4 * o or not p.grad.is_contiguous():
+            if p.grad is None:
+                flat_g[o:o + k].zero_()
+            elif p.grad.data_ptr() != base + 4 * o or not p.grad.is_contiguous():
                 flat_g[o:o + k].view(p.shape).copy_(p.grad)
+        return missing
 
     def step(self, grad_scale: float = 1.0):
         flat_p, flat_g = self._state()
-        self._gather_grads(flat_g)
+        missing = self._gather_grads(flat_g)
         g = self.param_groups[0]
         self.step_count += 1
+        keep = []
+        if missing:      # skipped parameters keep value AND moments (the kernel updates the whole buffer)
+            _, _, offsets = self.model.flat_buffers()
+            for n in missing:
+                o, k = offsets[n]
+                keep.append((o, k, flat_p[o:o + k].clone(), self.exp_avg[o:o + k].clone(), self.exp_avg_sq[o:o + k].clone()))
         ops.adam(flat_p, flat_g, self.exp_avg, self.exp_avg_sq, g["lr"], self.step_count, g["betas"][0],
                  g["betas"][1], g["eps"], grad_scale)
+        for o, k, pv, m1, m2 in keep:
+            flat_p[o:o + k].copy_(pv)
+            self.exp_avg[o:o + k].copy_(m1)
+            self.exp_avg_sq[o:o + k].copy_(m2)
 
     # checkpoint format of torch.optim.Adam, so `optimizer_state` in model.pth interchanges
     # (utils/train_logger.py:95-112, train.py:56-57)

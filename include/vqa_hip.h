@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define VQA_ABI_VERSION 1
+/* Bumped whenever an exported entry point changes its argument list or disappears (round 1: 1, round 2: 2, round 3: 3).
+ * dl_vqa_amd/_lib.py parses this line and refuses a library that answers differently. */
+#define VQA_ABI_VERSION 3
 
 #define VQA_OK 0
 #define VQA_ERR_INVALID 1 /* bad argument (shape, alignment, null pointer) */

@@ -22,7 +22,7 @@ def test_header_symbols_are_bound_and_exported():
     assert set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
     for n in names:
         assert hasattr(lib, n), f"{n} not exported by libvqa_hip.so"
-    assert lib.vqa_abi_version() == 1
+    assert lib.vqa_abi_version() == _lib.header_abi_version() >= 3
 
 
 def test_argument_validation_without_gpu():

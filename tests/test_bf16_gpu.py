@@ -185,10 +185,11 @@ def test_bf16_module_matches_bf16_oracle(do_option, train):
     print(f"[parity-bf16] worst gradient error {worst:.3e}")
 
 
-def test_bf16_configs3_architecture_matches_bf16_oracle():
-    """BASELINE.json configs[3]'s architecture (448x448 images, four conv blocks 64/128/256/512, Hq=Ha=Hc=1024, T=14,
-    A=1000) at B=2 in train mode with shared dropout masks: every bf16 kernel at the channel counts / tile shapes the
-    bf16 bench line runs.  Tolerances as in test_bf16_module_matches_bf16_oracle, wider for the depth (four rounding
+def test_bf16_four_block_448_matches_bf16_oracle():
+    """A DEEPER network than the one benchmarked (448x448 images, FOUR conv blocks 64/128/256/512 -> a 26x26 grid,
+    Hq=Ha=Hc=1024, T=14, A=1000) at B=2 in train mode with shared dropout masks: the bf16 kernels at a 512-channel block
+    and K up to 4.6e3.  (configs[3]'s own architecture -- the reference's three blocks, 54x54 grid -- is
+    test_bf16_configs3_bench_architecture below.)  Tolerances as in test_bf16_module_matches_bf16_oracle, wider for the depth (four rounding
     points per path instead of three, K up to 4.6e3 per conv output): logits 5e-4 absolute and at most half the
     bf16-vs-fp32 distance; gradients 5e-2 of the largest entry."""
     from oracle import vqa_oracle as O
@@ -225,6 +226,56 @@ def test_bf16_configs3_architecture_matches_bf16_oracle():
         e = float((p.grad.cpu() - ref).abs().max()) / scale
         d = float((g_f32[k] - ref).abs().max()) / scale
         print(f"[parity-bf16] configs[3] architecture grad {k}: vs bf16 oracle {e:.3e}; bf16 vs fp32 oracle {d:.3e}")
+        assert e < 5e-2, (k, e)
+
+
+def test_bf16_configs3_bench_architecture():
+    """BASELINE.json configs[3] as `bench.py --dtype bf16 --size 448` runs it: the reference's THREE conv blocks
+    3/64/128/256 (config.yaml:60) on 448x448 images -> 54x54 grid, P = 2 916 positions, Hq=Ha=Hc=1024, T=14, A=1000;
+    B=2, train mode with shared dropout masks.  These are the shapes of profiles/r0x_bf16_448_kernel_stats.txt: the
+    bf16 attention stage (gemm_bf16 row-group epilogue, att_score_*<2,true>, l2norm_fwd<true>) at P = 2 916 and the conv
+    kernels at 223 / 110-pixel maps (VERDICT r2 'weak' 1).
+    Parity for this row is UNPINNED by the reference (it has no bf16 path): the bf16 oracle rounds where the HIP path
+    rounds, so agreement shows 'same algorithm up to accumulation order'; the external anchor is the second
+    assertion -- the HIP result sits closer to the bf16 oracle than half the bf16-to-fp32 distance, and that distance
+    itself stays small against the logits' scale."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd import VqaNet
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    from tests.hip_masks import hip_masks
+    from tests.golden_util import full_cfg
+    cfg = full_cfg(1000)
+    assert cfg["image"]["num_channels"] == [3, 64, 128, 256]
+    V, B, S, T = 3000, 2, 448, 14
+    torch.manual_seed(12)
+    m = VqaNet(cfg, V, compute_dtype="bf16").to(DEV).train()
+    sd = {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}
+    v, q, a_idx, a_val, _, _, ql = O.synthetic_batch(B, S, T, V, 1000, seed=7)
+    y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
+    loss, _ = soft_ce_loss_and_score(y, a_idx.to(DEV), a_val.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ctx = m._last_ctx
+    assert ctx.Pn == 2916 and tuple(ctx.acts[1].shape[1:3]) == (223, 223) and tuple(ctx.acts[2].shape[1:3]) == (110, 110)
+    masks = hip_masks(m._engine, ctx.seed, B, T, ctx.acts[-1].shape[1], DEV)
+    y_ref, loss_ref, g_ref = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks, bf16=True)
+    y_f32, _, g_f32 = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks)
+    err = float((y.detach().cpu() - y_ref).abs().max())
+    dist = float((y_f32 - y_ref).abs().max())
+    print(f"[parity-bf16] configs[3] bench architecture (P=2916) logits |err| vs bf16 oracle {err:.3e}; bf16 vs fp32 oracle {dist:.3e}; "
+          f"logits scale {float(y_f32.abs().max()):.3e}")
+    assert err < 5e-4 and err < 0.5 * dist
+    assert dist < 2e-2 * max(float(y_f32.abs().max()), 1e-3)
+    assert abs(float(loss) - float(loss_ref)) < 5e-4
+    for k, p in m.named_parameters():
+        ref = g_ref[k]
+        scale = max(float(ref.abs().max()), 1e-12)
+        if k == "attention.x_conv.bias":
+            assert float(p.grad.abs().max()) < 1e-6
+            continue
+        e = float((p.grad.cpu() - ref).abs().max()) / scale
+        d = float((g_f32[k] - ref).abs().max()) / scale
+        print(f"[parity-bf16] configs[3] bench architecture grad {k}: vs bf16 oracle {e:.3e}; bf16 vs fp32 oracle {d:.3e}")
         assert e < 5e-2, (k, e)
 
 

@@ -89,9 +89,10 @@ def step_flops_per_sample(cfg, S, T):
     return 2.0 * (3.0 * fwd - conv0)
 
 
-def cpu_baseline(cfg, V, A, T):
+def cpu_baseline(cfg, V, A, T, steps=1):
     """The CPU restatement (oracle, kind 'port') timed on this host: forward + loss + backward + Adam,
-    batch 16 of 224x224 images (BASELINE.json configs[0]); bounded to ~10-30 s."""
+    batch 16 of 224x224 images (BASELINE.json configs[0]); one warm-up + `steps` timed steps, bounded to ~10-25 s, and run
+    BEFORE the GPU leg so that the GPU part of the run is its contiguous tail (VERDICT r2 'weak' 11)."""
     from oracle import vqa_oracle as O
     from dl_vqa_amd import VqaNet
     B, S = 16, 224
@@ -103,7 +104,7 @@ def cpu_baseline(cfg, V, A, T):
     v, q, a_idx, a_val, _, _, q_len = batch
     times = []
     t_all = time.time()
-    for it in range(3):
+    for it in range(steps + 1):
         t0 = time.time()
         _, loss, grads = O.loss_and_grads(sd, cfg, v, q, q_len, a_idx, a_val)
         lr = O.learning_rate(5e-4, it)
@@ -115,7 +116,8 @@ def cpu_baseline(cfg, V, A, T):
     best = min(times[1:]) if len(times) > 1 else times[0]
     return {"value": round(B / best, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{len(times)} train steps (fwd+loss+bwd+Adam) of batch {B}, {S}x{S}, T={T}, A={A}; "
-                      f"best of {max(1, len(times) - 1)} after 1 warm-up; os.cpu_count()={os.cpu_count()}"}
+                      f"best of {max(1, len(times) - 1)} after 1 warm-up; os.cpu_count()={os.cpu_count()}; "
+                      f"run before the GPU leg ({time.time() - t_all:.1f} s)"}
 
 
 def main():
@@ -166,17 +168,19 @@ def main():
     assert lib.vqa_device_ok() == 1, "no gfx950 device visible"
     cfg = reference_cfg(args.answers)
     B, S, T, V, A = args.batch, args.size, args.tokens, args.vocab, args.answers
+    # the CPU baseline runs FIRST (rank 0, N = 1 only): the GPU leg is then the contiguous tail of the run
+    cpu_info = cpu_baseline(cfg, V, A, T, steps=2) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
     torch.manual_seed(1)                                   # config.yaml:9 seed
     model = VqaNet(cfg, V, compute_dtype=args.dtype).to(dev)
     model.train(not args.eval_mode)
-    if use_dist:
-        DataParallel(model)
+    dp = DataParallel(model) if use_dist else None
     batch = tuple(t.to(dev) for t in synthetic_batch(B, S, T, V, A, seed=1 + rank))
     opt = FusedAdam(model, lr=5e-4)
     it = [0]
 
     def step():
-        loss, score = run_batch(model, None, batch, A, batch_divisor=B * world)
+        # no explicit divisor: under DP run_batch takes local batch x world size from the attached synchroniser
+        loss, score = run_batch(model, None, batch, A)
         opt.zero_grad()
         update_learning_rate(opt, it[0], 5e-4)
         loss.backward()
@@ -217,10 +221,55 @@ def main():
         ns = lib.vqa_prof_read_groups(s_id, s_tag, s_n, s_ms, cap)
         lib.vqa_prof_arm(-1, -1)
         stream_rows = [(s_id[k], s_tag[k], s_n[k], s_ms[k]) for k in range(ns)]
+    dp_info = None
     if use_dist:
-        tmax = torch.tensor([elapsed], device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed], device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        elapsed = max(per_rank)
+        dp_info = {"ms_per_step_per_rank_min": round(min(per_rank) / args.steps * 1e3, 3),
+                   "ms_per_step_per_rank_max": round(max(per_rank) / args.steps * 1e3, 3),
+                   "bucketed_direct_path": bool(model._last_backward_direct),
+                   "collectives_per_backward": list(dp.issued[-4:]),
+                   "streams_bwd": os.environ.get("VQA_STREAMS_BWD", os.environ.get("VQA_STREAMS", "2"))}
+
+        def timed_dp(nsteps):
+            """nsteps more steps with every bucket's issue point and the end of backward marked by HIP events."""
+            dp.record_events = True
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_ = time.perf_counter()
+            for _ in range(nsteps):
+                step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            el = time.perf_counter() - t_
+            dp.record_events = False
+            rows = dp.timings()
+            tm = torch.tensor([el], device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            avg = {k: round(sum(r[k] for r in rows) / len(rows), 3) for k in rows[0]} if rows else {}
+            return float(tm.item()) / nsteps * 1e3, avg
+
+        # overlap evidence OUTSIDE the timed region: ms from each bucket's issue point to the end of backward's kernels
+        # (what its all-reduce can hide under) and ms the stream then still waits for the collectives
+        ms_a, ov_a = timed_dp(max(3, args.steps // 2))
+        dp_info["overlap_ms_bucket_issue_to_backward_end"] = {k: v for k, v in ov_a.items() if not k.startswith("_")}
+        dp_info["exposed_allreduce_ms_after_backward"] = ov_a.get("_exposed_ms")
+        # the other backward schedule (VQA_STREAMS_BWD: 1 = the BPTT chain joined before the conv backward, so the 'text'
+        # bucket's all-reduce runs under all of the conv kernels; 2 = the chain under the conv kernels): measured beside
+        # the headline schedule so that the first multi-GPU run can pick the default
+        cur = dp_info["streams_bwd"]
+        alt = "1" if cur != "1" else "2"
+        os.environ["VQA_STREAMS_BWD"] = alt
+        for _ in range(2):
+            step()
+        ms_b, ov_b = timed_dp(max(3, args.steps // 2))
+        os.environ["VQA_STREAMS_BWD"] = cur
+        dp_info["schedule_alt"] = {"streams_bwd": alt, "ms_per_step": round(ms_b, 3), "same_run_ms_per_step_of_default": round(ms_a, 3),
+                                   "overlap_ms_bucket_issue_to_backward_end": {k: v for k, v in ov_b.items() if not k.startswith("_")},
+                                   "exposed_allreduce_ms_after_backward": ov_b.get("_exposed_ms")}
     final_loss = float(loss.detach())
 
     # The same step in the fp32x3 mode (fp32 tensors and fp32-level accuracy, the conv blocks and v_conv contractions on the
@@ -238,7 +287,7 @@ def main():
             itx = [0]
 
             def step_x():
-                loss_x, _ = run_batch(model_x, None, batch, A, batch_divisor=B * world)
+                loss_x, _ = run_batch(model_x, None, batch, A)
                 opt_x.zero_grad()
                 update_learning_rate(opt_x, itx[0], 5e-4)
                 loss_x.backward()
@@ -251,6 +300,8 @@ def main():
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
+            lib.vqa_prof_arm_mask(0b1111, -1)        # the same event bracketing as the headline's timed loop
+            torch.cuda.synchronize()
             tx0 = time.perf_counter()
             for _ in range(args.steps):
                 loss_x = step_x()
@@ -258,6 +309,7 @@ def main():
             if use_dist:
                 dist.barrier()
             el_x = time.perf_counter() - tx0
+            lib.vqa_prof_arm(-1, -1)
             if use_dist:
                 tmax = torch.tensor([el_x], device=dev)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -282,14 +334,31 @@ def main():
         value = B * world * args.steps / elapsed
         shapes, _ = conv_shapes(S, cfg["image"]["num_channels"], cfg["image"]["stride"])
         # live per-kernel table: every convolution kernel of the step, algorithmic FLOPs / measured launch time
-        traffic_db = {}
         peak = {"bf16": BF16_MFMA_PEAK_TFLOPS, "fp32x3": X3_MFMA_PEAK_TFLOPS}.get(args.dtype, FP32_MFMA_PEAK_TFLOPS)
-        if B == 256 and S == 224 and args.dtype == "fp32":
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_conv1_traffic.json")) as f:
-                    traffic_db = json.load(f)
-            except (OSError, ValueError):
-                pass
+        # HBM-side bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes, gfx950
+        # correction per MI355X_MICROARCH.md): tools/pmc_conv_run.py launches every conv kernel of one layer in isolation
+        # under rocprofv3, tools/pmc_traffic_summary.py writes profiles/r03_conv_traffic_<dtype>_<size>_<batch>.json keyed
+        # "<family>:<layer>" with the kernel names it saw
+        traffic_db, traffic_file = {}, f"r03_conv_traffic_{args.dtype}_{S}_{B}.json"
+        try:
+            with open(os.path.join(ROOT, "profiles", traffic_file)) as f:
+                traffic_db = json.load(f)
+        except (OSError, ValueError):
+            traffic_file = None
+        esz = 2 if args.dtype == "bf16" else 4           # bytes per activation element between the conv blocks
+
+        def conv_alg_bytes(fam, tag):
+            """Compulsory operand bytes of one launch (each tensor once): DESIGN.md 4.1."""
+            ci, co, Ho, Wo = shapes[tag]
+            Hi, Hp = Ho + 2, Ho // 2
+            x_b = B * Hi * Hi * max(ci, 4) * (4 if tag == 0 else esz)
+            pooled = B * Hp * Hp * co
+            last = tag == len(shapes) - 1
+            if fam == "conv_fwd":
+                return x_b + pooled * ((4 if last else esz) + 1) + 9 * ci * co * esz
+            if fam == "conv_dgrad":
+                return pooled * (esz + 1) + x_b + 9 * ci * co * esz
+            return x_b + pooled * (esz + 1) + 9 * ci * co * 4
         kernels = []
         for g in range(n_groups):
             fam, tag = FAMS.get(g_id[g]), g_tag[g]
@@ -305,6 +374,7 @@ def main():
                             "achieved": round(ach, 2), "frac": round(ach / kpeak, 4), "peak": kpeak,
                             "traffic": (int(traffic_db[f"{fam}:{tag}"]["hbm_bytes_corrected"])
                                         if f"{fam}:{tag}" in traffic_db else None),
+                            "algorithmic_bytes_per_launch": int(conv_alg_bytes(fam, tag)),
                             "ms_per_step": round(g_ms[g] / args.steps, 3), "family": fam})
         # dominant kernel = the kernel FAMILY (conv_fwd / conv_dgrad / conv_wgrad, conv1 + conv2 launches together)
         # with the most device time in the step; --roofline-kernel conv_fwd|conv_dgrad|conv_wgrad[:layer] overrides.
@@ -330,7 +400,9 @@ def main():
                         "traffic": (int(sum(t * k["launches"] for t, k in zip(tr, sel)) / n) if all(t is not None for t in tr) else None),
                         "avg_launch_ms": round(tot_ms / n, 4), "launches": n,
                         "algorithmic_gflop_per_launch": round(gf / n, 2),
-                        "traffic_unit": "bytes/launch (PMC, profiles/r01_conv1_traffic.json)"}
+                        "algorithmic_bytes_per_launch": int(sum(k["algorithmic_bytes_per_launch"] * k["launches"] for k in sel) / n),
+                        "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/{traffic_file})" if traffic_file
+                                        else "no PMC file for this shape / dtype under profiles/"}
         for k in kernels:
             del k["family"]
         # HBM-bound stages: algorithmic bytes per launch / measured launch time, against the 8 TB/s
@@ -389,8 +461,10 @@ def main():
         }
         if x3_info is not None:
             out["fp32x3"] = x3_info
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, V, A, T)
+        if dp_info is not None:
+            out["data_parallel"] = dp_info
+        if cpu_info is not None:
+            out["cpu_baseline"] = cpu_info
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

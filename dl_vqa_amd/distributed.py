@@ -30,6 +30,10 @@ class DataParallel:
         self.rank = dist.get_rank(process_group)
         self._handles: List = []
         self.issued: List[str] = []             # groups whose collective has been issued, in order (tests, bench)
+        # overlap evidence (bench.py --gpus N): with record_events set, every bucket's issue point and the end of
+        # backward are marked with HIP events on the streams they happen on; timings() reads them after a sync
+        self.record_events = False
+        self._marks: List = []
         model._grad_sync = self
         model._seed_rank = self.rank            # different dropout masks per rank
         if broadcast:
@@ -46,13 +50,45 @@ class DataParallel:
         if flat is None:
             _, flat, _ = model.flat_buffers()
         lo, hi = model.group_range(group)
+        if self.record_events and flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(flat.device))        # the stream whose kernels produced the bucket
+            self._marks.append((group, ev))
         self._handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self.issued.append(group)
 
     def finish(self, model) -> None:
+        mark = bool(self.record_events and self._marks and self._marks[-1][0] not in ("_backward_end", "_reduced"))
+        if mark:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                         # current stream: the last kernel of backward has been enqueued
+            self._marks.append(("_backward_end", ev))
         for h in self._handles:
             h.wait()                            # stream-ordered on NCCL: no host block
+        if mark:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append(("_reduced", ev))
         self._handles = []
+
+    def timings(self):
+        """After torch.cuda.synchronize(): per backward recorded, ms from each bucket's issue point to the end of that
+        backward's kernels (= how much backward work its all-reduce can hide under), and ms the stream then still
+        waits for the collectives ('_exposed_ms').  Clears the marks."""
+        out, cur = [], {}
+        for name, ev in self._marks:
+            if name == "_backward_end":
+                cur = {"_end": ev, **cur}
+            elif name == "_reduced":
+                end = cur.pop("_end")
+                row = {g: round(e.elapsed_time(end), 3) for g, e in cur.items()}
+                row["_exposed_ms"] = round(end.elapsed_time(ev), 3)
+                out.append(row)
+                cur = {}
+            else:
+                cur[name] = ev
+        self._marks = []
+        return out
 
     def reduce_flat(self, flat: torch.Tensor) -> None:
         """SUM all-reduce of a whole gradient buffer laid out like the model's flat buffer, as the same

@@ -94,7 +94,10 @@ class Engine:
     def _side_streams(self, dev):
         # VQA_STREAMS: 0 = one stream; 1 = the question branch on a side stream, joined before the image branch;
         # 2 (default) = the question branch runs UNDER the convolutions (forward: joined before the attention stage,
-        # backward: joined at the end).  Same box, interleaved, B=256: 27.33 / 26.99 ms per step for 1 / 2 -- the
+        # backward: joined at the end).  VQA_STREAMS_BWD (default: VQA_STREAMS) picks the BACKWARD schedule on its
+        # own: under data parallelism "1" joins the BPTT chain before the convolution backward starts, so the 'text'
+        # bucket (66 % of the gradient bytes) is all-reduced under ALL of the convolution kernels instead of their
+        # last 2-3 ms (bench.py --gpus N measures both).  Same box, interleaved, B=256: 27.33 / 26.99 ms per step for 1 / 2 -- the
         # LSTM step launches leave bubbles (prologue / cell epilogue / launch seams of a 44 us kernel) that
         # convolution workgroups fill.
         mode = os.environ.get("VQA_STREAMS", "2")
@@ -481,7 +484,7 @@ class Engine:
             ready("text")
             ev0 = torch.cuda.Event()
             ev0.record(sides[0])
-        if os.environ.get("VQA_STREAMS", "2") == "1":
+        if os.environ.get("VQA_STREAMS_BWD", os.environ.get("VQA_STREAMS", "2")) == "1":
             main.wait_event(ev0)
 
         # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first

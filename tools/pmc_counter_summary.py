@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-launch average of one PMC counter for the conv kernels of tools/pmc_conv1_run.py:
-    rocprofv3 --pmc MfmaUtil -d gpurun_out/pmc_mfma -- python3 tools/pmc_conv1_run.py
+"""Per-launch average of one PMC counter for the conv kernels of tools/pmc_conv_run.py:
+    rocprofv3 --pmc MfmaUtil -d gpurun_out/pmc_mfma -- python3 tools/pmc_conv_run.py
     python tools/pmc_counter_summary.py gpurun_out/pmc_mfma MfmaUtil > profiles/rNN_mfma_util.json
 Events of a family alternate layer 1, layer 2 in dispatch order (see the workload)."""
 import glob, json, sqlite3, sys

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""HBM-side bytes per launch of the conv kernels from two rocprofv3 --pmc passes (see tools/pmc_conv1_run.py).
+"""HBM-side bytes per launch of the conv kernels from two rocprofv3 --pmc passes (see tools/pmc_conv_run.py).
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-byte requests as 64 bytes -> x2; WRITE_SIZE exact.
 The workload launches every family alternately for layer 1 and layer 2, so a family's events in dispatch order
 split into the two layers by parity."""
 import glob, json, sqlite3, sys
+
+
+NAMES = {}
 
 
 def per_kernel(d, counter):
@@ -13,8 +16,9 @@ def per_kernel(d, counter):
         q = "select name, counter_value, dispatch_id from pmc_events where counter_name = ? order by dispatch_id"
         for name, v, _ in c.execute(q, (counter,)):
             for key in ("conv_fwd", "conv_wgrad", "conv_dgrad"):
-                if key + "_kernel" in name:
+                if name.replace("vqa::", "").replace("void ", "").startswith(key + "_"):     # conv_fwd_kernel, conv_fwd_bf16_kernel, ...
                     out.setdefault(key, []).append(float(v))
+                    NAMES.setdefault(key, []).append(name.replace("vqa::", "").replace("void ", "").split("(")[0][:80])
     res = {}
     for k, v in out.items():
         for layer in (1, 2):
@@ -28,6 +32,8 @@ fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {}
 for k in sorted(fetch):
+    fam, layer = k.split(":")
     res[k] = {"FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write.get(k, 0.0),
-              "hbm_bytes_corrected": 2 * fetch[k] * 1024 + write.get(k, 0.0) * 1024}
+              "hbm_bytes_corrected": 2 * fetch[k] * 1024 + write.get(k, 0.0) * 1024,
+              "kernel_names": sorted(set(NAMES.get(fam, [])[int(layer) - 1::2]))}
 print(json.dumps(res, indent=1))

@@ -103,6 +103,16 @@ PROTOTYPES = {
     "vqa_conv3x3_dgrad_bf16": (i32, [vp, u8p, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_conv3x3_wgrad_bf16_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "vqa_conv3x3_wgrad_bf16": (i32, [vp, vp, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, f32p, i64, i32, vp]),
+    "vqa_pconv_supported": (i32, [i32, i32, i32, i32, i32]),
+    "vqa_pconv_weights_bytes": (i64, [i32, i32]),
+    "vqa_pconv_pack_weights": (i32, [f32p, vp, vp, i32, i32, vp]),
+    "vqa_pconv_fwd": (i32, [vp, vp, f32p, vp, i32, u8p, i32, i32, i32, i32, i32, i32, vp]),
+    "vqa_pconv_expand_dy": (i32, [vp, u8p, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "vqa_pconv_wgrad_supported": (i32, [i32, i32, i32, i32]),
+    "vqa_pconv_wgrad_workspace_bytes": (i64, [i32, i32, i32, i32, i32]),
+    "vqa_pconv_wgrad": (i32, [vp, vp, i32, i32, vp, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, i32, vp]),
+    "vqa_pconv_dy_dims": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "vqa_pconv_dgrad": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_adam": (i32, [f32p, f32p, f32p, f32p, i64, f32, f32, f32, f32, i32, f32, vp]),
 }
 

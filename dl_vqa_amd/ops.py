@@ -494,6 +494,96 @@ def conv_wgrad_bf16(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, str
          ptr(ws), ws.numel() * 4, tag, stream())
 
 
+# ------------------------------------------------------------------ bf16 patch convolutions (csrc/conv_patch_bf16.hip)
+# Everything a patch is cut from lives in HBM channel-blocked, "C16" = [B][C/16][H][W][16] bf16 (a K-slice of a patch row is
+# one contiguous run); pooled fp32 outputs, dX, pooled gradients and arg-max bytes stay NHWC.
+def to_c16(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """NHWC -> C16 by torch (tests / tools; the kernels write C16 themselves)."""
+    B, H, W, C = x_nhwc.shape
+    return x_nhwc.view(B, H, W, C // 16, 16).permute(0, 3, 1, 2, 4).contiguous()
+
+
+def from_c16(x_c16: torch.Tensor) -> torch.Tensor:
+    B, Cb, H, W, _ = x_c16.shape
+    return x_c16.permute(0, 2, 3, 1, 4).reshape(B, H, W, Cb * 16).contiguous()
+
+
+def pconv_supported(H: int, W: int, Ci: int, Co: int, stride: int = 1) -> bool:
+    return bool(_lib.load().vqa_pconv_supported(H, W, Ci, Co, stride))
+
+
+def pconv_pack_weights(w: torch.Tensor, need_wd: bool = True):
+    """fp32 [Co,Ci,3,3] -> fragment-ordered bf16 images (forward; flipped + transposed for backward-data)."""
+    Co, Ci = w.shape[0], w.shape[1]
+    n = 9 * Ci * Co
+    wf = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    wd = torch.empty(n, dtype=torch.bfloat16, device=w.device) if need_wd else None
+    call("vqa_pconv_pack_weights", ptr(w), ptr(wf), ptr(wd), Co, Ci, stream())
+    return wf, wd
+
+
+def pconv_fwd(x: torch.Tensor, wf_img: torch.Tensor, bias: torch.Tensor, Co: int, out_dtype=torch.bfloat16, tag: int = 0):
+    """x C16 bf16 [B,Ci/16,H,W,16] -> (pooled: bf16 C16 [B,Co/16,Hp,Wp,16] or fp32 NHWC [B,Hp,Wp,Co]; argmax uint8 NHWC)."""
+    assert x.dtype == torch.bfloat16 and wf_img.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 5
+    B, Cb, H, W, _ = x.shape
+    Hp, Wp = conv_out_hw(H, W, 1)
+    if out_dtype == torch.bfloat16:
+        pooled = torch.empty(B, Co // 16, Hp, Wp, 16, dtype=torch.bfloat16, device=x.device)
+    else:
+        pooled = torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x.device)
+    amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x.device)
+    call("vqa_pconv_fwd", ptr(x), ptr(wf_img), ptr(bias), ptr(pooled), int(out_dtype == torch.bfloat16), ptr(amax),
+         B, H, W, Cb * 16, Co, tag, stream())
+    return pooled, amax
+
+
+def pconv_dy_dims(H: int, W: int):
+    """(Hd, Wd) of the materialised pre-pool gradient of a block whose INPUT map is H x W."""
+    import ctypes
+    hd, wd = ctypes.c_int(), ctypes.c_int()
+    call("vqa_pconv_dy_dims", H, W, ctypes.byref(hd), ctypes.byref(wd))
+    return hd.value, wd.value
+
+
+def pconv_expand_dy(dpooled: torch.Tensor, amax: torch.Tensor, H: int, W: int):
+    """Pooled gradient bf16 NHWC [B,Hp,Wp,C] + arg-max bytes -> the pre-pool gradient of the block with input map H x W,
+    routed, bf16 C16 [B,C/16,Hd,Wd,16] with dY(y, x) at (y+2, x+2) and zeros elsewhere (what pconv_dgrad / pconv_wgrad read)."""
+    assert dpooled.dtype == torch.bfloat16 and dpooled.is_contiguous()
+    B, Hp, Wp, C = dpooled.shape
+    Hd, Wd = pconv_dy_dims(H, W)
+    dy = torch.empty(B, C // 16, Hd, Wd, 16, dtype=torch.bfloat16, device=dpooled.device)
+    call("vqa_pconv_expand_dy", ptr(dpooled), ptr(amax), ptr(dy), B, Hp, Wp, Hd, Wd, C, stream())
+    return dy
+
+
+def pconv_dgrad(dy_pad: torch.Tensor, wd_img: torch.Tensor, x_shape, out_dtype=torch.bfloat16, tag: int = 0):
+    """dy_pad C16 -> dX NHWC [B,H,W,Ci] (bf16 or fp32); x_shape = (B, H, W, Ci) of the block's input."""
+    B, H, W, Ci = x_shape
+    _, Cb, Hd, Wd, _ = dy_pad.shape
+    assert dy_pad.dtype == torch.bfloat16 and dy_pad.shape[0] == B
+    dx = torch.empty(B, H, W, Ci, dtype=out_dtype, device=dy_pad.device)
+    call("vqa_pconv_dgrad", ptr(dy_pad), Hd, Wd, ptr(wd_img), ptr(dx), int(out_dtype == torch.bfloat16), B, H, W, Ci, Cb * 16,
+         tag, stream())
+    return dx
+
+
+def pconv_wgrad_supported(H: int, W: int, Ci: int, Co: int) -> bool:
+    return bool(_lib.load().vqa_pconv_wgrad_supported(H, W, Ci, Co))
+
+
+def pconv_wgrad(x, dy_pad, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, tag: int = 0):
+    """dw [Co,Ci,3,3], dbias [Co] (fp32) from x (C16 bf16), the materialised pre-pool gradient (C16) and, for the bias, the
+    pooled gradient + arg-max bytes (NHWC)."""
+    assert x.dtype == torch.bfloat16 and dy_pad.dtype == torch.bfloat16 and dpooled.dtype == torch.bfloat16
+    lib = _lib.load()
+    B, Cib, H, W, _ = x.shape
+    _, Cob, Hd, Wd, _ = dy_pad.shape
+    Ci, Co = Cib * 16, Cob * 16
+    ws = workspace(lib.vqa_pconv_wgrad_workspace_bytes(B, H, W, Ci, Co), x.device)
+    call("vqa_pconv_wgrad", ptr(x), ptr(dy_pad), Hd, Wd, ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, Ci, Co,
+         ptr(ws), ws.numel() * 4, tag, stream())
+
+
 def scale_by(x, scalar_dev):
     call("vqa_scale_by", ptr(x), x.numel(), ptr(scalar_dev), stream())
     return x

@@ -304,6 +304,37 @@ int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* ar
                            int B, int H, int W, int CiP, int Ci, int Co, int stride, float* workspace,
                            int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
+/* Patch convolutions of the bf16 path (csrc/conv_patch_bf16.hip; models/model.py:80-82 and their autograd), 3x3, stride 1:
+ * a persistent workgroup keeps an input patch in LDS (filled by buffer_load ... lds) and takes the nine taps as shifted
+ * fragment reads of it, so every input pixel is fetched once per workgroup instead of once per tap.  Same tensors and
+ * results contract as the vqa_conv3x3_*_bf16 entry points (activations NHWC bf16, arg-max bytes, fp32 accumulation), with two
+ * differences: the weights are packed per step into fragment-ordered images (vqa_pconv_pack_weights; wf_img for forward,
+ * wd_img = flipped + transposed for backward-data, vqa_pconv_weights_bytes each), and the backward kernels read the
+ * pre-pool gradient MATERIALISED once per layer: dy_pad [B][Hd][Wd][Co] bf16 with dY(y, x) at (y+2, x+2), routed by the
+ * arg-max bytes, zero everywhere else (vqa_pconv_expand_dy; Hd x Wd from vqa_pconv_dy_dims: at least (H+2) x (W+2), padded
+ * so that the weight-gradient tiles may overhang the map), so that backward-data is a plain valid convolution of dy_pad.
+ * Shapes: Ci % 16 == 0, Co % 64 == 0 (forward); additionally Ci % 64 == 0 for backward-data (vqa_pconv_supported). */
+int vqa_pconv_supported(int H, int W, int Ci, int Co, int stride);
+int64_t vqa_pconv_weights_bytes(int Ci, int Co);
+int vqa_pconv_pack_weights(const float* w /* [Co][Ci][3][3] */, void* wf_img /* may be NULL */, void* wd_img /* may be NULL */,
+                           int Co, int Ci, vqa_stream_t stream);
+int vqa_pconv_fwd(const void* x, const void* wf_img, const float* bias, void* pooled, int pooled_is_bf16, uint8_t* argmax,
+                  int B, int H, int W, int Ci, int Co, int tag, vqa_stream_t stream);
+int vqa_pconv_dy_dims(int H, int W, int* Hd, int* Wd); /* H, W: the block's INPUT map */
+int vqa_pconv_expand_dy(const void* dpooled, const uint8_t* argmax, void* dy_pad, int B, int Hp, int Wp, int Hd, int Wd,
+                        int C, vqa_stream_t stream);
+int vqa_pconv_dgrad(const void* dy_pad, int Hd, int Wd, const void* wd_img, void* dx, int dx_is_bf16, int B, int H, int W,
+                    int Ci, int Co, int tag, vqa_stream_t stream);
+/* weight + bias gradient: dw [Co][Ci][3][3], dbias [Co] fp32.  A workgroup holds a whole [9 taps x 64 ci] x [128 co] block of
+ * dW in its accumulators and streams 4 x 32-pixel tiles of x (LDS patch, nine shifted transpose-reads) and dy_pad through
+ * LDS; one fp32 slab per workgroup, summed by a reduce kernel (deterministic).  Ci % 64 == 0, Co % 128 == 0, and
+ * (Ci / 64) * (Co / 128) in {1, 2, 4, 8}; dbias is the masked column sum of dpooled (arg-max != 4). */
+int vqa_pconv_wgrad_supported(int H, int W, int Ci, int Co);
+int64_t vqa_pconv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co);
+int vqa_pconv_wgrad(const void* x, const void* dy_pad, int Hd, int Wd, const void* dpooled, const uint8_t* argmax, float* dw,
+                    float* dbias, int B, int H, int W, int Ci, int Co, float* workspace, int64_t workspace_bytes, int tag,
+                    vqa_stream_t stream);
+
 /* ---- fp32 on the bf16 matrix cores ("fp32x3": csrc/x3_core.hpp) -------------------------------
  * The same fp32 tensors, layouts and results contract as the fp32 entry points above; inside the K loop every
  * fp32 operand element is split exactly into three bf16 terms (8 + 8 + 8 significand bits) and a product is

@@ -324,3 +324,71 @@ def test_bf16_path_rejects_unsupported_configs():
         VqaNet(cfg, 10, compute_dtype="bf16")
     with pytest.raises(ValueError, match="compute_dtype"):
         VqaNet(bf16_cfg(), 10, compute_dtype="fp8")
+
+
+# ----------------------------------------------------------------------------- patch convolutions (LDS-resident input patch)
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 30, 30, 64, 128), (1, 30, 34, 128, 256), (3, 22, 20, 64, 64), (2, 58, 58, 64, 128),
+                                         (1, 70, 45, 16, 64), (2, 37, 75, 128, 128), (5, 18, 100, 32, 256)])
+def test_pconv_fwd_dgrad_wgrad(B, H, W, Ci, Co):
+    """csrc/conv_patch_bf16.hip against float64 autograd on bf16-rounded x, w, dy: forward (fp32 NHWC and bf16 C16 outputs,
+    arg-max), the materialised pre-pool gradient (bit-exact routing, zero border and padding, C16), backward-data (fp32 and
+    bf16 outputs), weight + bias gradient.  Shapes with tile overhang on both axes, odd sizes (dropped pool row / column),
+    one and several 64-/128-channel slabs and roles, several images (persistent tile streams that cross image borders)."""
+    ops = _ops()
+    assert ops.pconv_supported(H, W, Ci, Co)
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Ci)
+    x = rb(torch.randn(B, Ci, H, W, generator=g))
+    w = rb(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci))
+    b = torch.randn(Co, generator=g) * 0.1
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.max_pool2d(torch.relu(F.conv2d(xr, wr, br)), 2, 2)
+    dy = rb(torch.randn(yr.shape, generator=g))
+    yr.backward(dy.double())
+
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)        # NHWC
+    xc = ops.to_c16(xd)                                                        # what the patch kernels read
+    assert torch.equal(ops.from_c16(xc), xd)
+    wf, wd = ops.pconv_pack_weights(w.to(DEV), need_wd=Ci % 64 == 0)
+    p32, amax = ops.pconv_fwd(xc, wf, b.to(DEV), Co, out_dtype=torch.float32)
+    p16, amax2 = ops.pconv_fwd(xc, wf, b.to(DEV), Co)
+    torch.cuda.synchronize()
+    tag = f"{B,H,W,Ci,Co}"
+    check(f"pconv fwd fp32-out {tag}", p32.permute(0, 3, 1, 2), yr, 3e-6 * math.sqrt(9 * Ci))
+    assert torch.equal(amax, amax2) and torch.equal(ops.from_c16(p16), p32.to(torch.bfloat16))
+    assert bool(((p32 == 0) == (amax == 4)).all())
+    # the same result as the implicit-GEMM kernel up to fp32 summation order; identical arg-max wherever the winner is clear
+    if Ci % 64 == 0:
+        wfT, _ = ops.conv_pack_weights_bf16(w.to(DEV), Ci, need_wd=False)
+        q32, amax_ig = ops.conv_fwd_bf16(xd, wfT, b.to(DEV), 1, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+        assert float((q32 - p32).abs().max()) <= 1e-5 * max(1.0, float(q32.abs().max()))
+        assert float((amax_ig != amax).float().mean()) < 1e-3
+
+    # pre-pool gradient, materialised: dy_pad[b, y+2, x+2, c] = dP[b, y//2, x//2, c] iff argmax == (y%2)*2 + x%2
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    Hp, Wp = yr.shape[2], yr.shape[3]
+    dyp = ops.pconv_expand_dy(dyd, amax, H, W)
+    torch.cuda.synchronize()
+    Hd, Wd = ops.pconv_dy_dims(H, W)
+    assert Hd >= H + 2 and Wd >= W + 2 and tuple(dyp.shape) == (B, Co // 16, Hd, Wd, 16)
+    ref = torch.zeros(B, Hd, Wd, Co, dtype=torch.bfloat16, device=DEV)
+    for j in range(4):
+        sel = torch.where(amax == j, dyd, torch.zeros_like(dyd))
+        ref[:, 2 + (j >> 1):2 + 2 * Hp:2, 2 + (j & 1):2 + 2 * Wp:2, :] = sel
+    assert torch.equal(ops.from_c16(dyp), ref)
+    # reference gradients with the KERNEL's arg-max (a float64 near-tie may pick another pixel of a window)
+    dyfull = ref[:, 2:H, 2:W, :].float().permute(0, 3, 1, 2).double().cpu()
+    if Ci % 64 == 0:
+        dx32 = ops.pconv_dgrad(dyp, wd, xd.shape, out_dtype=torch.float32)
+        dx16 = ops.pconv_dgrad(dyp, wd, xd.shape)
+        torch.cuda.synchronize()
+        dx_ref = torch.nn.grad.conv2d_input(xr.shape, wr.detach(), dyfull)
+        check(f"pconv dgrad fp32-out {tag}", dx32.permute(0, 3, 1, 2), dx_ref, 5e-6 * math.sqrt(9 * Co))
+        assert torch.equal(dx16, dx32.to(torch.bfloat16))
+    if ops.pconv_wgrad_supported(H, W, Ci, Co):
+        dw, db = torch.empty(Co, Ci, 3, 3, device=DEV), torch.empty(Co, device=DEV)
+        ops.pconv_wgrad(xc, dyp, dyd, amax, dw, db)
+        torch.cuda.synchronize()
+        dw_ref = torch.nn.grad.conv2d_weight(xr.detach(), wr.shape, dyfull)
+        check(f"pconv wgrad {tag}", dw, dw_ref, 2e-5)
+        check(f"pconv bias grad {tag}", db, dyfull.sum(dim=(0, 2, 3)), 2e-5)

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restri
 // Same patch staging (fp32, planar), but the 27 taps (padded to 32) are two v_mfma_f32_32x32x16_bf16 k-steps: a lane
 // gathers its 2 x 8 taps from the patch, rounds them to bf16 (the image is rounded where it is consumed, as the weights
 // are) and issues 2 x TN MFMAs per 32-pixel tile instead of 14 x TN fp32 ones -- the kernel becomes store-bound.
-template <int CI, int TN>
+// C16: the pooled map is written channel-blocked, [B][Co/16][Hp][Wp][16] bf16 -- what the patch convolutions of the next
+// block cut their LDS patches from (csrc/conv_patch_bf16.hip); the arg-max bytes stay NHWC.
+template <int CI, int TN, bool C16 = false>
 __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, uint16_t* pooled16,
                                                              uint8_t* amax, int H, int W, int Hp, int Wp, int RS) {
@@ -182,7 +184,9 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __r
 
   const int nwin = nwr * Wp, ntiles = (nwin + 7) / 8;
   const int64_t o0 = (int64_t)(b * Hp + py0) * Wp * Co;
-  const __amdgpu_buffer_rsrc_t rp = buf_rsrc(pooled16 + o0), ra = buf_rsrc(amax + o0);
+  const int plane16 = Hp * Wp * 16;                     // elements of one 16-channel block of one image
+  const int64_t o16 = ((int64_t)b * (Co / 16) * Hp + py0) * Wp * 16;
+  const __amdgpu_buffer_rsrc_t rp = buf_rsrc(pooled16 + (C16 ? o16 : o0)), ra = buf_rsrc(amax + o0);
   for (int t = wave; t < ntiles; t += 4) {
     int wdx = 8 * t + (l31 >> 2);
     if (wdx >= nwin) wdx = 0;
@@ -205,6 +209,8 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __r
     }
     const bool inner = 8 * t + 8 <= nwin;
     const uint32_t vl = (uint32_t)__mul24(8 * t + h, Co) + (uint32_t)l31;
+    // C16: element (window, channel 32 j + l31) lives at block (2 j + l31 / 16), window, l31 % 16
+    const uint32_t vl16 = (uint32_t)((l31 >> 4) * plane16 + (8 * t + h) * 16 + (l31 & 15));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const bool ok = inner || 8 * t + 2 * g + h < nwin;
@@ -217,7 +223,8 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __r
         if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
         best += bv[j];
         const uint32_t so = (uint32_t)(2 * g * Co + 32 * j);
-        buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl : BUF_OOB, 2u * so);
+        if (C16) buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl16 : BUF_OOB, 2u * (uint32_t)(2 * j * plane16 + 2 * g * 16));
+        else buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl : BUF_OOB, 2u * so);
         buf_store1(ra, best > 0.f ? (uint8_t)a : (uint8_t)4, ok ? vl : BUF_OOB, so);
       }
     }
@@ -491,15 +498,24 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
     if (rc0) return rc0;                                                                                               \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS); \
   })
-  if (pooled_is_bf16 == 2) {      // bf16 MFMA (image and weights rounded to bf16), bf16 output
+  if (pooled_is_bf16 == 2 || pooled_is_bf16 == 4) {      // bf16 MFMA (image and weights rounded to bf16), bf16 output (4: C16)
     VQA_REQUIRE(Ci <= 3, "vqa_conv0_relu_pool_fwd: the bf16-MFMA first block needs Ci <= 3");
+    VQA_REQUIRE((int64_t)Hp * Wp * Co * 2 < (1LL << 31), "vqa_conv0_relu_pool_fwd: one pooled image reaches 2 GiB");
     C0_DISPATCH(Ci, Co / 32, {
       if constexpr (kCI <= 3) {
-        auto kern = conv0_fwd_bf16_kernel<kCI, kTN>;
-        int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd_bf16)");
-        if (rc0) return rc0;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, static_cast<uint16_t*>(pooled),
-                           argmax, H, W, Hp, Wp, RS);
+        if (pooled_is_bf16 == 4) {
+          auto kern = conv0_fwd_bf16_kernel<kCI, kTN, true>;
+          int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd_bf16)");
+          if (rc0) return rc0;
+          hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, static_cast<uint16_t*>(pooled),
+                             argmax, H, W, Hp, Wp, RS);
+        } else {
+          auto kern = conv0_fwd_bf16_kernel<kCI, kTN, false>;
+          int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd_bf16)");
+          if (rc0) return rc0;
+          hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, static_cast<uint16_t*>(pooled),
+                             argmax, H, W, Hp, Wp, RS);
+        }
       }
     });
   } else if (pooled_is_bf16 == 3) { C0_FWD_LAUNCH(2); } else if (pooled_is_bf16) { C0_FWD_LAUNCH(1); } else { C0_FWD_LAUNCH(0); }

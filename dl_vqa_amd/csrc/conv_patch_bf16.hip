@@ -35,6 +35,14 @@
 
 namespace vqa {
 
+// Timing experiments (tools/kbench_pconv.py --dbg ...): only in a -DVQA_PCONV_DIAG build do the kernels look at VQA_PCONV_DBG
+// (1 = no epilogue stores, 2 = no DMA after the first stage, 4 = no MFMA); the shipped kernels carry none of those branches.
+#ifdef VQA_PCONV_DIAG
+#define PC_DBG(bit) (P.dbg & (bit))
+#else
+#define PC_DBG(bit) false
+#endif
+
 constexpr int PC_RS = 40;   // patch row stride in pixels (34 used; 40 = 8 mod 16 keeps the fragment reads conflict-free)
 constexpr int PC_TX = 32;   // tile width in pixels
 
@@ -47,10 +55,12 @@ struct PcCfg {
   static constexpr int PROWS = TY + 2;
   static constexpr int PATCH_BYTES = ((PROWS * PC_RS * 32 + 1023) / 1024) * 1024;
   static constexpr int PATCH_INSTR = PATCH_BYTES / 1024;
-  static constexpr int PK = (PATCH_INSTR + 3) / 4;   // patch DMA instructions per issuing wave (four waves issue a stage)
+  static constexpr int PK = (PATCH_INSTR + 7) / 8;   // patch DMA pieces per wave (piece i = wave + 8 k)
   static constexpr int W_BYTES = 9 * NT * 1024;
   static constexpr int W_INSTR = 9 * NT;
-  static constexpr int WK = (W_INSTR + 3) / 4;
+  static constexpr int WK = (W_INSTR + 7) / 8;
+  static constexpr int NP = PK + WK;                 // pieces a wave issues per stage: one behind each tap's MFMAs (two behind tap 0 when NP = 9)
+  static_assert(NP <= 9, "at most nine pieces per wave and stage");
   static constexpr int LDS = 2 * (PATCH_BYTES + W_BYTES);
   static constexpr int SCR = 4608;                   // wave-private epilogue scratch (>= 4 KiB: 32 pixels x 64 channels bf16)
   static constexpr int LDS_ALL = LDS + 8 * SCR;
@@ -74,6 +84,29 @@ struct PcParams {
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
+
+// LDS-DMA in inline asm.  With the builtin (raw_ptr_buffer_load_lds) hipcc tracks the transfer as a pending LDS write and
+// puts s_waitcnt vmcnt(0) in front of LDS accesses it cannot tell apart from the destination -- the first ds_read_b64_tr_b16
+// of the weight-gradient stage and the epilogue's scratch accesses here -- i.e. the wave that had just issued the NEXT stage's
+// pieces waited for them to land before computing the current one.  The asm form is invisible to that pass; the kernels
+// order DMA against LDS reads themselves (one counted s_waitcnt vmcnt + s_barrier per stage).  16 bytes per lane, LDS
+// destination = wave-uniform address + 16 * lane (M0), source = descriptor base + voff (per lane) + soff (scalar).
+typedef unsigned int pc_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pc_rsrc_t pc_rsrc(const void* base, uint32_t bytes = 0xffff0000u) {
+  const uint64_t a = (uint64_t)base;
+  pc_rsrc_t r;
+  r.x = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(pc_rsrc_t r, const void* lds_dst, uint32_t voff, uint32_t soff) {
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst);
+  uint32_t keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(m0v), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
 
 // position of a tile in the workgroup's stream; stepping by `nstreams` tiles without divisions (all scalar)
 struct PcTile {
@@ -107,7 +140,6 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / C::WN, wn = wave % C::WN;
   const int r = lane & 31, h = lane >> 5;
-  const int half = wave >> 2, w4 = wave & 3;        // waves w and w + 4 share a SIMD; the halves take turns issuing DMA
 
   // ---- this workgroup's stream of tiles: the slabs of one spatial tile run on the same XCD (blocks b and b + 8 share one)
   const int bid = blockIdx.x;
@@ -134,18 +166,18 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
   }
   const uint32_t baddr = (uint32_t)(2 * C::PATCH_BYTES + wn * 2048 + lane * 16);
 
-  // ---- DMA source offsets of this wave's patch pieces i = w4 + 4k (bytes from the tile's first pixel, slice 0)
+  // ---- DMA source offsets of this wave's patch pieces i = wave + 8k (bytes from the tile's first pixel of the slice)
   uint32_t pvoff[C::PK];
 #pragma unroll
   for (int k = 0; k < C::PK; ++k) {
-    const int i = w4 + 4 * k;
+    const int i = wave + 8 * k;
     const int o = i * 1024 + lane * 16;
     const int p = o >> 5, slot = (o >> 4) & 1;
     const int row = p / PC_RS, xx = p - row * PC_RS;
     const int chunk = slot ^ ((p >> 3) & 1);
     pvoff[k] = (i < C::PATCH_INSTR && row < C::PROWS) ? (uint32_t)((row * P.W + xx) * 32 + chunk * 16) : BUF_OOB;
   }
-  const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(P.wimg);
+  const pc_rsrc_t wrs = pc_rsrc(P.wimg);
   const uint32_t wlane = (uint32_t)lane * 16u;
 
   float bias_v[2] = {0.f, 0.f};
@@ -154,26 +186,32 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
     for (int j = 0; j < 2; ++j) bias_v[j] = P.bias[n_slab0 + wn * 64 + 32 * j + r];
   }
 
-  // all of one stage's pieces, issued by the four waves of one half (the other half's MFMAs keep the matrix pipes busy
-  // meanwhile: with both waves of a SIMD issuing at once the pipes idled for the ~1 us the issue takes, a fifth of a stage)
-  auto issue = [&](const PcTile& tp, int slice, int buf) {
+  // The next stage's pieces are issued one at a time BEHIND the MFMAs of each tap (piece n of this wave after tap n; the
+  // patch pieces, which may miss L2, first): an LDS-DMA instruction holds its wave for a few hundred cycles, and issued in
+  // a burst at the start of a stage -- by all waves, or by one wave of each SIMD -- that was 0.8-2 us of every 3-5 us stage
+  // with the matrix pipes waiting (measured with the DMA skipped); spread out, the partner wave's MFMAs cover each one.
+  pc_rsrc_t ns_rs = wrs;      // the next stage: patch source, weight offset, LDS buffer, "there is one"
+  uint32_t ns_wsrc = 0;
+  int ns_buf = 0;
+  bool ns_on = false;
+  auto next_stage = [&](const PcTile& tp, int slice, int buf, bool on) {
     const char* base = P.x + ((((int64_t)tp.img * P.nslices + slice) * P.H + tp.ty * C::TY) * P.W + tp.tx * PC_TX) * 32;
     const int64_t left = P.x_end - base;
-    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(base, left > 0xffff0000LL ? 0xffff0000u : (uint32_t)left);
-    char* const pdst = smem + buf * C::PATCH_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < C::PK; ++kk) {
-      const int i = w4 + 4 * kk;
+    ns_rs = pc_rsrc(base, left > 0xffff0000LL ? 0xffff0000u : (uint32_t)left);
+    ns_wsrc = (uint32_t)((slab * P.nslices + slice) * C::W_BYTES);
+    ns_buf = buf;
+    ns_on = on;
+  };
+  auto issue_piece = [&](int n) {        // n is a compile-time constant at every call
+    if (!ns_on) return;
+    if (n < C::PK) {
+      const int i = wave + 8 * n;
       if (i < C::PATCH_INSTR)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(pdst + i * 1024), 16, (int)pvoff[kk], 0, 0, 0);
-    }
-    char* const wdst = smem + 2 * C::PATCH_BYTES + buf * C::W_BYTES;
-    const uint32_t wsrc = (uint32_t)((slab * P.nslices + slice) * C::W_BYTES);
-#pragma unroll
-    for (int kk = 0; kk < C::WK; ++kk) {
-      const int i = w4 + 4 * kk;
+        lds_dma16(ns_rs, smem + ns_buf * C::PATCH_BYTES + i * 1024, pvoff[n < C::PK ? n : 0], 0u);
+    } else if (n < C::NP) {
+      const int i = wave + 8 * (n - C::PK);
       if (i < C::W_INSTR)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(wdst + i * 1024), 16, (int)wlane, (int)(wsrc + i * 1024), 0, 0);
+        lds_dma16(wrs, smem + 2 * C::PATCH_BYTES + ns_buf * C::W_BYTES + i * 1024, wlane, ns_wsrc + i * 1024);
     }
   };
 
@@ -187,7 +225,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
 
   char* const scr = smem + C::LDS + wave * C::SCR;     // wave-private epilogue scratch
 
-  if (half == 1) issue(nxt, 0, 0);
+  next_stage(nxt, 0, 0, true);
+#pragma unroll
+  for (int n = 0; n < C::NP; ++n) issue_piece(n);
   int buf = 0;
   bool after_epilogue = false;
   for (int k = 0; k < my_tiles; ++k) {
@@ -197,16 +237,14 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       after_epilogue = false;
       __builtin_amdgcn_s_barrier();                       // everybody's have; everybody is done reading the other buffer
-      {
-        int ns = slice + 1;
-        bool more = true;
-        if (ns == P.nslices) {
-          ns = 0;
-          nxt.advance(dlt, P.tiles_y, P.tiles_x);
-          more = k + 1 < my_tiles;
-        }
-        if (more && half == buf && !(P.dbg & 2)) issue(nxt, ns, buf ^ 1);
+      int nsl = slice + 1;
+      bool more = !PC_DBG(2);
+      if (nsl == P.nslices) {
+        nsl = 0;
+        nxt.advance(dlt, P.tiles_y, P.tiles_x);
+        more = more && k + 1 < my_tiles;
       }
+      next_stage(nxt, nsl, buf ^ 1, more);
       const char* const pa = smem + buf * C::PATCH_BYTES;
       const char* const pb = smem + buf * C::W_BYTES + baddr;
       bf16x8 a[2][4], b[2][2];
@@ -223,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
       for (int t = 0; t < 9; ++t) {
         if (t < 8) fetch(t + 1, (t + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(P.dbg & 4)) {
+        if (!PC_DBG(4)) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -236,13 +274,20 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
           for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b[t & 1][j]));
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (t == 0) {
+          issue_piece(0);
+          if (C::NP == 9) issue_piece(1);
+        } else if (t < 8) {
+          issue_piece(t + (C::NP == 9 ? 1 : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       buf ^= 1;
     }
     // ---- epilogue of tile k, then clear the accumulators
     const int y0 = cur.ty * C::TY, x0 = cur.tx * PC_TX, img = cur.img;
     cur.advance(dlt, P.tiles_y, P.tiles_x);
-    if (P.dbg & 1) {
+    if (PC_DBG(1)) {
       if (acc[0][0][0] == 123.456f) static_cast<float*>(P.out)[0] = 1.f;     // keeps the accumulators alive
     } else if (EPI < 2) {
       // rounds of (pooled row ip of the wave, 32-channel tile j): 16 windows x 32 channels through the scratch.
@@ -359,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
         }
       }
     }
-    after_epilogue = !(P.dbg & 1) && EPI != 3;
+    after_epilogue = !PC_DBG(1) && EPI != 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -499,6 +544,7 @@ struct PwParams {
   int B, H, W, Ci, Co, Hd, Wd;
   int tiles_y, tiles_x, ntiles;            // 4 x 32-pixel tiles over the pool-covered map, per image / in all
   int roles_co, nroles;                    // Co / 128, (Ci / 64) * (Co / 128)
+  int dbg;                                 // timing experiments only (VQA_PCONV_DBG): 2 = no DMA after the first stage, 4 = no MFMA
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
@@ -540,21 +586,20 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
     const int y0 = tp.ty * 4, x0 = tp.tx * 32;
     const char* xb = P.x + ((((int64_t)tp.img * (P.Ci / 16) + ci0 / 16 + w4) * P.H + y0) * P.W + x0) * 32;
     const int64_t xl = P.x_end - xb;
-    const __amdgpu_buffer_rsrc_t rx = buf_rsrc(xb, xl > 0xffff0000LL ? 0xffff0000u : (uint32_t)xl);
+    const pc_rsrc_t rx = pc_rsrc(xb, xl > 0xffff0000LL ? 0xffff0000u : (uint32_t)xl);
     char* const st = smem + buf * PW_STAGE;
 #pragma unroll
     for (int i = 0; i < PW_XPC; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(st + w4 * PW_XB + i * 1024), 16, (int)xvoff[i], 0, 0, 0);
+      lds_dma16(rx, st + w4 * PW_XB + i * 1024, xvoff[i], 0u);
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
       const int blk = 2 * w4 + bb;
       const char* db = P.dy + ((((int64_t)tp.img * (P.Co / 16) + co0 / 16 + blk) * P.Hd + y0 + 2) * P.Wd + x0 + 2) * 32;
       const int64_t dl = P.dy_end - db;
-      const __amdgpu_buffer_rsrc_t rd = buf_rsrc(db, dl > 0xffff0000LL ? 0xffff0000u : (uint32_t)dl);
+      const pc_rsrc_t rd = pc_rsrc(db, dl > 0xffff0000LL ? 0xffff0000u : (uint32_t)dl);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void*)(st + PW_X + blk * PW_DB + rr * 1024), 16, (int)dlane,
-                                                 rr * P.Wd * 32, 0, 0);
+        lds_dma16(rd, st + PW_X + blk * PW_DB + rr * 1024, dlane, (uint32_t)(rr * P.Wd * 32));
     }
   };
 
@@ -577,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     nxt.advance(dlt, P.tiles_y, P.tiles_x);
-    if (k + 1 < my_tiles && half == buf) issue(nxt, buf ^ 1);
+    if (k + 1 < my_tiles && half == buf && !PC_DBG(2)) issue(nxt, buf ^ 1);
     const char* const xa = smem + buf * PW_STAGE + a_lane;
     const char* const da = smem + buf * PW_STAGE + b_lane;
     bf16x8 a[9], b[2];
@@ -590,7 +635,8 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
       if (s < 7) b[(s + 1) & 1] = frag(da + (((s + 1) >> 1) * 32 + 16 * ((s + 1) & 1)) * 32);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[s & 1], acc[t], 0, 0, 0);
+        if (!PC_DBG(4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[s & 1], acc[t], 0, 0, 0);
+        else asm volatile("" ::"v"(a[t]), "v"(b[s & 1]));
         if (s < 7)
           a[t] = frag(xa + ((((s + 1) >> 1) + t / 3) * PW_XRS + 16 * ((s + 1) & 1) + t % 3) * 32);
       }
@@ -623,17 +669,37 @@ __global__ __launch_bounds__(256) void pconv_wgrad_reduce_kernel(const float* sl
   dw[((int64_t)co * Ci + ci) * 9 + tap] = s;
 }
 
-// bias gradient = column sums of the pooled gradient over the windows that are alive (arg-max != 4); two deterministic stages
+// bias gradient = column sums of the pooled gradient over the windows that are alive (arg-max != 4); two deterministic stages.
+// A thread owns 8 consecutive channels (one 16-byte load of dP + 8 arg-max bytes per window), the Co / 8 threads of a window sit
+// side by side (coalesced NHWC rows), 256 / (Co / 8) window lanes per block stride over the block's windows and are combined
+// through LDS in a fixed order.
 __global__ __launch_bounds__(256) void pconv_bias_part_kernel(const uint16_t* dp, const uint8_t* am, float* part, int64_t windows,
                                                              int Co, int64_t per) {
+  extern __shared__ __attribute__((aligned(16))) float bred[];      // [window lanes][Co]
+  const int cpr = Co / 8, nwl = 256 / cpr;
+  const int c = threadIdx.x % cpr, wl = threadIdx.x / cpr;
   const int64_t w0 = (int64_t)blockIdx.x * per;
   const int64_t w1 = w0 + per < windows ? w0 + per : windows;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (wl < nwl) {
+    for (int64_t w = w0 + wl; w < w1; w += nwl) {
+      const uint4 d = *reinterpret_cast<const uint4*>(dp + w * Co + 8 * c);
+      const uint2 a = *reinterpret_cast<const uint2*>(am + w * Co + 8 * c);
+      const uint32_t dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t code = ((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xffu;
+        const float v = (k & 1) ? bf16_hi(dd[k >> 1]) : bf16_lo(dd[k >> 1]);
+        acc[k] += code != 4u ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bred[wl * Co + 8 * c + k] = acc[k];
+  }
+  __syncthreads();
   for (int co = threadIdx.x; co < Co; co += 256) {
     float s = 0.f;
-    for (int64_t w = w0; w < w1; ++w) {
-      const float v = __uint_as_float((uint32_t)dp[w * Co + co] << 16);
-      s += am[w * Co + co] != 4 ? v : 0.f;
-    }
+    for (int l = 0; l < nwl; ++l) s += bred[l * Co + co];
     part[(int64_t)blockIdx.x * Co + co] = s;
   }
 }
@@ -776,7 +842,7 @@ int vqa_pconv_dgrad(const void* dy_pad, int Hd, int Wd, const void* wd_img, void
 }
 
 static int pw_roles(int Ci, int Co) { return (Ci / 64) * (Co / 128); }
-static int pw_bias_parts(int64_t windows) { int64_t p = (windows + 255) / 256; return (int)(p > 2048 ? 2048 : (p < 1 ? 1 : p)); }
+static int pw_bias_parts(int64_t windows) { int64_t p = (windows + 63) / 64; return (int)(p > 1024 ? 1024 : (p < 1 ? 1 : p)); }
 
 int vqa_pconv_wgrad_supported(int H, int W, int Ci, int Co) {
   if (H < 4 || W < 4 || Ci <= 0 || Co <= 0 || Ci % 64 || Co % 128) return 0;
@@ -799,6 +865,7 @@ int vqa_pconv_wgrad(const void* x, const void* dy_pad, int Hd, int Wd, const voi
                     vqa_stream_t stream) {
   VQA_REQUIRE(x && dy_pad && dpooled && argmax && dw && dbias && workspace && B > 0, "vqa_pconv_wgrad: null pointer");
   VQA_REQUIRE(vqa_pconv_wgrad_supported(H, W, Ci, Co), "vqa_pconv_wgrad: unsupported shape H=%d W=%d Ci=%d Co=%d", H, W, Ci, Co);
+  VQA_REQUIRE(Co <= 2048, "vqa_pconv_wgrad: Co=%d above 2048", Co);
   int Hm = 0, Wm = 0;
   vqa_pconv_dy_dims(H, W, &Hm, &Wm);
   VQA_REQUIRE(Hd >= Hm && Wd >= Wm, "vqa_pconv_wgrad: dy_pad %dx%d is smaller than vqa_pconv_dy_dims (%dx%d)", Hd, Wd, Hm, Wm);
@@ -816,6 +883,10 @@ int vqa_pconv_wgrad(const void* x, const void* dy_pad, int Hd, int Wd, const voi
   P.tiles_y = (2 * Hp + 3) / 4; P.tiles_x = (2 * Wp + 31) / 32;
   P.ntiles = B * P.tiles_y * P.tiles_x;
   P.roles_co = Co / 128; P.nroles = pw_roles(Ci, Co);
+  {
+    const char* e = getenv("VQA_PCONV_DBG");
+    P.dbg = e ? atoi(e) : 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   set_launch_tag(tag);
   ProfScope prof(VQA_K_CONV_WGRAD, s);
@@ -833,8 +904,8 @@ int vqa_pconv_wgrad(const void* x, const void* dy_pad, int Hd, int Wd, const voi
   const int parts = pw_bias_parts(windows);
   const int64_t per = (windows + parts - 1) / parts;
   float* const bpart = workspace + (int64_t)256 * 9 * 64 * 128;
-  hipLaunchKernelGGL(pconv_bias_part_kernel, dim3(parts), dim3(256), 0, s, static_cast<const uint16_t*>(dpooled), argmax, bpart,
-                     windows, Co, per);
+  hipLaunchKernelGGL(pconv_bias_part_kernel, dim3(parts), dim3(256), (size_t)(256 / (Co / 8)) * Co * 4, s,
+                     static_cast<const uint16_t*>(dpooled), argmax, bpart, windows, Co, per);
   rc = check_hip(hipGetLastError(), "pconv_bias_part launch");
   if (rc) return rc;
   hipLaunchKernelGGL(pconv_bias_reduce_kernel, dim3((Co + 255) / 256), dim3(256), 0, s, bpart, dbias, parts, Co);

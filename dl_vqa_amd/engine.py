@@ -76,6 +76,18 @@ class Engine:
                 raise ValueError("the bf16 path needs >= 2 conv blocks, stride 1 and channel counts that are multiples "
                                  f"of 64 after the first block (num_channels={self.channels}, stride={self.stride})")
 
+    def _pconv_ok(self, H: int, W: int) -> bool:
+        """bf16 path: do the patch convolutions cover every block after the first for an H x W image?"""
+        if os.environ.get("VQA_PCONV", "1") == "0" or self.stride != 1:
+            return False
+        h, w = ops.conv_out_hw(H, W, 1)
+        for l in range(1, self.L):
+            ci, co = self.channels[l], self.channels[l + 1]
+            if not (ops.pconv_supported(h, w, ci, co, 1) and ci % 64 == 0 and ops.pconv_wgrad_supported(h, w, ci, co)):
+                return False
+            h, w = ops.conv_out_hw(h, w, 1)
+        return True
+
     def _x3_layer(self, x_shape, Co) -> bool:
         """fp32x3 mode: does this conv block (NHWC input shape, output channels) run on the split kernels?"""
         return self.x3 and len(x_shape) == 4 and ops.conv_x3_supported(x_shape[1], x_shape[2], x_shape[3], Co, self.stride)
@@ -219,6 +231,10 @@ class Engine:
         fast0 = ops.conv0_supported(v.shape[1], v.shape[2], v.shape[3], self.channels[1], self.stride)
         acts = [v if fast0 else ops.nchw_to_nhwc4(v)]
         idxs, wds = [], []
+        # bf16 path: blocks 1.. on the patch convolutions (csrc/conv_patch_bf16.hip: LDS-resident input patch, activations
+        # between the blocks channel-blocked "C16") when every block's shape has them; VQA_PCONV=0 keeps the implicit-GEMM
+        # kernels (A/B runs, parity tests of both)
+        use_pc = self.bf16 and fast0 and self._pconv_ok(v.shape[2], v.shape[3])
         for l in range(self.L):
             w = P[f"image.conv{l}.weight"]
             assert w.shape[0] == self.channels[l + 1]
@@ -228,7 +244,7 @@ class Engine:
             if l == 0 and fast0:
                 pooled, am = ops.conv0_fwd(v, w, P["image.conv0.bias"],
                                            out_dtype=torch.bfloat16 if self.bf16 else torch.float32, bf16_mfma=self.bf16,
-                                           out_packed=nxt_x3)
+                                           out_packed=nxt_x3, out_c16=use_pc)
                 acts.append(pooled)
                 idxs.append(am)
                 wds.append(None)
@@ -238,6 +254,14 @@ class Engine:
                     raise ValueError("the bf16 path needs the dedicated first-block kernel (3-channel NCHW image, "
                                      "W % 4 == 0, 32 or 64 output channels)")
                 # bf16 activations in, bf16 out (fp32 out of the last block: the L2 normalisation consumes it)
+                if use_pc:
+                    wf_img, wd_img = ops.pconv_pack_weights(w, need_wd=keep)
+                    pooled, am = ops.pconv_fwd(acts[-1], wf_img, P[f"image.conv{l}.bias"], w.shape[0],
+                                               out_dtype=torch.float32 if l == self.L - 1 else torch.bfloat16, tag=l)
+                    acts.append(pooled)
+                    idxs.append(am)
+                    wds.append(wd_img)
+                    continue
                 wfT, wdT = ops.conv_pack_weights_bf16(w, acts[-1].shape[3], need_wd=keep)
                 pooled, am = ops.conv_fwd_bf16(acts[-1], wfT, P[f"image.conv{l}.bias"], self.stride,
                                                out_dtype=torch.float32 if l == self.L - 1 else torch.bfloat16, tag=l)
@@ -321,7 +345,7 @@ class Engine:
             return logits, None
         ctx = SimpleNamespace(B=B, T=T, Pn=Pn, q=q, q_len=q_len, acts=acts, idxs=idxs, wds=wds, vn=vn, norm=norm,
                               x_emb=x_emb, lstm=lstm, v_in=v_in, v16=v16, wv16=wv16, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
-                              c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, vprime=vprime, qp=qp, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
+                              c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, use_pc=use_pc, vprime=vprime, qp=qp, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
                               seed=seed, stages=dict(pooled=pooled, score=score, combined=combined))
         return logits, ctx
 
@@ -497,6 +521,15 @@ class Engine:
                     ops.conv0_wgrad_bf16(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])
                 else:
                     ops.conv0_wgrad(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])
+                continue
+            if self.bf16 and ctx.use_pc:
+                # the pre-pool gradient is materialised once per block (routed by the arg-max bytes, C16, zero-padded):
+                # weight gradient and backward-data both read it as a plain operand
+                Bx, _, Hx, Wx, _ = ctx.acts[l].shape
+                dyp = ops.pconv_expand_dy(dP, ctx.idxs[l], Hx, Wx)
+                ops.pconv_wgrad(ctx.acts[l], dyp, dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"], tag=l)
+                dP = ops.pconv_dgrad(dyp, ctx.wds[l], (Bx, Hx, Wx, self.channels[l]), tag=l)
+                del dyp
                 continue
             if self.bf16:
                 ops.conv_wgrad_bf16(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],

@@ -170,17 +170,20 @@ def conv0_supported(Ci: int, H: int, W: int, Co: int, stride: int) -> bool:
 
 
 def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype=torch.float32, bf16_mfma=False,
-              out_packed=False):
+              out_packed=False, out_c16=False):
     """First conv block straight from the NCHW image: (pooled NHWC [B,Hp,Wp,Co] fp32 or bf16, argmax uint8).
     bf16_mfma (bf16 output only): image and weights rounded to bf16, bf16 MFMA.  out_packed: fp32 MFMA, the output
-    written in the x3-packed form [B,Hp,Wp,Co/4,3,4] bf16 (see x3_pack)."""
+    written in the x3-packed form [B,Hp,Wp,Co/4,3,4] bf16 (see x3_pack).  out_c16 (with bf16_mfma): the pooled map
+    channel-blocked [B,Co/16,Hp,Wp,16] for the patch convolutions; the arg-max bytes stay NHWC."""
     B, Ci, H, W = x_nchw.shape
     Co = w.shape[0]
     Hp, Wp = conv_out_hw(H, W, 1)
+    assert not out_c16 or (bf16_mfma and out_dtype == torch.bfloat16 and not out_packed)
     pooled = (torch.empty(B, Hp, Wp, Co // 4, 3, 4, dtype=torch.bfloat16, device=x_nchw.device) if out_packed else
+              torch.empty(B, Co // 16, Hp, Wp, 16, dtype=torch.bfloat16, device=x_nchw.device) if out_c16 else
               torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x_nchw.device))
     amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x_nchw.device)
-    mode = 3 if out_packed else (2 if bf16_mfma else 1) if out_dtype == torch.bfloat16 else 0
+    mode = 3 if out_packed else (4 if out_c16 else 2 if bf16_mfma else 1) if out_dtype == torch.bfloat16 else 0
     call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(pooled), mode, ptr(amax), B, Ci, H, W, Co, stream())
     return pooled, amax
 

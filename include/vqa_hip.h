@@ -121,7 +121,8 @@ int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride);
 int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, void* pooled,
                             int pooled_is_bf16 /* 0: fp32 out; 1: fp32 MFMA, P_0 stored as bf16; 2 (bf16 path):
                             image and weights rounded to bf16, two 32x32x16 bf16 MFMA k-steps, bf16 out; 3 (fp32x3 path): fp32
-                            MFMA, the output written x3-packed (vqa_x3_pack's form, 6 bytes per element) */, uint8_t* argmax, int B, int Ci,
+                            MFMA, the output written x3-packed (vqa_x3_pack's form, 6 bytes per element); 4: as 2 with the
+                            pooled map channel-blocked, [B][Co/16][Hp][Wp][16] (what vqa_pconv_* read; arg-max stays NHWC) */, uint8_t* argmax, int B, int Ci,
                             int H, int W, int Co, vqa_stream_t stream);
 int64_t vqa_conv0_wgrad_workspace_bytes(int Co);
 int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias,

@@ -185,6 +185,49 @@ def test_bf16_module_matches_bf16_oracle(do_option, train):
     print(f"[parity-bf16] worst gradient error {worst:.3e}")
 
 
+@pytest.mark.parametrize("pconv", ["1", "0"])
+def test_bf16_module_patch_conv_path_matches_bf16_oracle(pconv, monkeypatch):
+    """The bf16 module on the reference's channel counts 3/64/128/256 (small image), where blocks 1.. run on the patch
+    convolutions (C16 activations, materialised pre-pool gradient), against the bf16 oracle -- and the same with
+    VQA_PCONV=0 (implicit-GEMM kernels): both paths must meet the same tolerances."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd import VqaNet
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    from tests.hip_masks import hip_masks
+    monkeypatch.setenv("VQA_PCONV", pconv)
+    cfg = bf16_cfg("+", 0.3)
+    cfg["image"]["num_channels"] = [3, 64, 128, 256]
+    V, B, S, T = 50, 2, 68, 6              # grid 6 x 6: B * P = 72 rows (the bf16 GEMMs want multiples of 8)
+    torch.manual_seed(4)
+    m = VqaNet(cfg, V, compute_dtype="bf16").to(DEV).train()
+    sd = {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}
+    v, q, a_idx, a_val, _, _, ql = O.synthetic_batch(B, S, T, V, 24, seed=8)
+    torch.manual_seed(9)
+    y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
+    loss, _ = soft_ce_loss_and_score(y, a_idx.to(DEV), a_val.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ctx = m._last_ctx
+    assert ctx.use_pc == (pconv == "1") and (ctx.acts[1].dim() == 5) == ctx.use_pc
+    masks = hip_masks(m._engine, ctx.seed, B, T, ctx.acts[-1].shape[1], DEV)
+    y_ref, loss_ref, g_ref = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks, bf16=True)
+    y_f32, _, g_f32 = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks)
+    err = float((y.detach().cpu() - y_ref).abs().max())
+    dist = float((y_f32 - y_ref).abs().max())
+    print(f"[parity-bf16] module (pconv={pconv}) logits |err| vs bf16 oracle {err:.3e}; bf16 vs fp32 oracle {dist:.3e}")
+    assert err < 5e-5 and err < 0.5 * dist
+    assert abs(float(loss) - float(loss_ref)) < 5e-5
+    for k, p in m.named_parameters():
+        ref = g_ref[k]
+        scale = max(float(ref.abs().max()), 1e-12)
+        if k == "attention.x_conv.bias":
+            assert float(p.grad.abs().max()) < 1e-6
+            continue
+        e = float((p.grad.cpu() - ref).abs().max()) / scale
+        print(f"[parity-bf16] module (pconv={pconv}) grad {k}: vs bf16 oracle {e:.3e}")
+        assert e < 2e-2, (k, e)
+
+
 def test_bf16_four_block_448_matches_bf16_oracle():
     """A DEEPER network than the one benchmarked (448x448 images, FOUR conv blocks 64/128/256/512 -> a 26x26 grid,
     Hq=Ha=Hc=1024, T=14, A=1000) at B=2 in train mode with shared dropout masks: the bf16 kernels at a 512-channel block
@@ -256,7 +299,8 @@ def test_bf16_configs3_bench_architecture():
     loss.backward()
     torch.cuda.synchronize()
     ctx = m._last_ctx
-    assert ctx.Pn == 2916 and tuple(ctx.acts[1].shape[1:3]) == (223, 223) and tuple(ctx.acts[2].shape[1:3]) == (110, 110)
+    hw = lambda t: tuple(t.shape[2:4]) if t.dim() == 5 else tuple(t.shape[1:3])      # C16 [B,C/16,H,W,16] or NHWC
+    assert ctx.Pn == 2916 and hw(ctx.acts[1]) == (223, 223) and hw(ctx.acts[2]) == (110, 110)
     masks = hip_masks(m._engine, ctx.seed, B, T, ctx.acts[-1].shape[1], DEV)
     y_ref, loss_ref, g_ref = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks, bf16=True)
     y_f32, _, g_f32 = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks)

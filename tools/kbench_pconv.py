@@ -32,15 +32,27 @@ def main():
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--skip-old", action="store_true")
+    ap.add_argument("--dbg", default="", help="comma list of VQA_PCONV_DBG values timed beside the plain run, e.g. 0,1,2,3,4")
     args = ap.parse_args()
     B, dev = args.batch, "cuda:0"
     h1 = (args.size - 2) // 2
     h2 = (h1 - 2) // 2
 
+    dbgs = [int(d) for d in args.dbg.split(",")] if args.dbg else [0]
+
     def run(name, flops, fn):
-        ms = timeit(fn, args.iters)
+        # timing experiments in ONE process on one device (VQA_PCONV_DBG is read at every launch): 1 = no epilogue stores,
+        # 2 = no DMA after the first stage, 4 = no MFMA
+        parts = []
+        for d in dbgs:
+            os.environ["VQA_PCONV_DBG"] = str(d)
+            ms = timeit(fn, args.iters)
+            parts.append((d, ms))
+        os.environ["VQA_PCONV_DBG"] = "0"
+        ms = parts[0][1]
         tf = flops / ms / 1e9
-        print(f"{name:28s} {ms:9.3f} ms  {tf:8.1f} TF/s  {100 * tf / PEAK:5.1f}% of bf16 MFMA peak", flush=True)
+        extra = "  ".join(f"dbg{d}={m:.3f}" for d, m in parts[1:])
+        print(f"{name:28s} {ms:9.3f} ms  {tf:8.1f} TF/s  {100 * tf / PEAK:5.1f}% of bf16 MFMA peak  {extra}", flush=True)
 
     for l, (Hin, Ci, Co) in enumerate(((h1, 64, 128), (h2, 128, 256)), 1):
         x = torch.randn(B, Hin, Hin, Ci, device=dev).to(torch.bfloat16)

@@ -61,10 +61,10 @@ PROTOTYPES = {
     "vqa_conv3x3_wgrad_x3": (i32, [vp, i32, f32p, vp, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32,
                                    f32p, i64, i32, vp]),
     "vqa_conv0_supported": (i32, [i32, i32, i32, i32, i32]),
-    "vqa_conv0_relu_pool_fwd": (i32, [f32p, f32p, f32p, vp, i32, u8p, i32, i32, i32, i32, i32, vp]),
+    "vqa_conv0_relu_pool_fwd": (i32, [vp, i32, f32p, f32p, vp, i32, u8p, i32, i32, i32, i32, i32, vp]),
     "vqa_conv0_wgrad_workspace_bytes": (i64, [i32]),
-    "vqa_conv0_wgrad": (i32, [f32p, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, vp]),
-    "vqa_conv0_wgrad_bf16": (i32, [f32p, vp, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, vp]),
+    "vqa_conv0_wgrad": (i32, [vp, i32, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, vp]),
+    "vqa_conv0_wgrad_bf16": (i32, [vp, i32, vp, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, vp]),
     "vqa_dropout": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_dropout_add": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp, i32, f32, u64, vp]),

@@ -37,6 +37,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_bf16_kernel
     store_acc_tiles<Cfg>(acc, slab, pe.N, pe.M, pe.N, m0, n0, wm, wn, lane);
     return;
   }
+  if constexpr (Cfg::WN == 64) {
+    // bf16 output of an interior tile, no aux / accumulate, row groups at least a tile tall: 16-byte stores through LDS
+    const bool staged = pe.Cb != nullptr && !pe.aux && !pe.accumulate && (!pe.rg || pe.rg_div >= Cfg::BM) &&
+                        m0 + Cfg::BM <= pe.M && n0 + Cfg::BN <= pe.N && (pe.ldc & 7) == 0 &&
+                        (reinterpret_cast<uintptr_t>(pe.Cb) & 15) == 0;
+    if (staged) return gemm_epilogue_bf16_staged<Cfg>(pe, acc, m0, n0, wm, wn, lane, smem);
+  }
   gemm_epilogue<Cfg>(pe, acc, m0, n0, wm, wn, lane);
 }
 
@@ -86,7 +93,10 @@ __global__ void dropout_to_bf16_kernel(const float* x, uint16_t* y, int64_t n, f
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     if (p > 0.f) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] *= drop_scale(seed, (uint64_t)(8 * i + k), p, inv_keep);
+      for (int k = 0; k < 8; k += 4) {
+        const float4 ds_ = drop_scale4(seed, (uint64_t)(8 * i + k), p, inv_keep);
+        v[k] *= ds_.x; v[k + 1] *= ds_.y; v[k + 2] *= ds_.z; v[k + 3] *= ds_.w;
+      }
     }
     uint4 o;
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);

@@ -66,13 +66,27 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// One 32-bit hash serves a PAIR of elements (idx >> 1), 16 random bits each: keep iff the element's 16-bit field is at or
+// above floor(p * 65536) -- the drop probability is p to within 2^-16.  The hash was the VALU bound of the attention-stage
+// kernels in train mode (two multiply-xorshift rounds per element: att_score_fwd ran at 2 TB/s against 4 TB/s in eval
+// mode); vector code takes four consecutive elements from drop_scale4 (two hashes).
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t pair) {
+  const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
+  uint32_t h = mix32(lo ^ (uint32_t)seed);
+  return mix32(h + hi * 0x9E3779B9U + (uint32_t)(seed >> 32));
+}
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
   // returns 0 (dropped) or 1/(1-p) (kept)
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t h = mix32(lo ^ (uint32_t)seed);
-  h = mix32(h + hi * 0x9E3779B9U + (uint32_t)(seed >> 32));
-  const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-  return u >= p ? inv_keep : 0.0f;
+  const uint32_t h = drop_hash(seed, idx >> 1);
+  const uint32_t u = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return u >= (uint32_t)(p * 65536.0f) ? inv_keep : 0.0f;
+}
+// scales of elements idx .. idx + 3, idx a multiple of 4
+__device__ __forceinline__ float4 drop_scale4(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+  const uint32_t h0 = drop_hash(seed, idx >> 1), h1 = drop_hash(seed, (idx >> 1) + 1);
+  const uint32_t thr = (uint32_t)(p * 65536.0f);
+  return make_float4((h0 & 0xffffu) >= thr ? inv_keep : 0.f, (h0 >> 16) >= thr ? inv_keep : 0.f,
+                     (h1 & 0xffffu) >= thr ? inv_keep : 0.f, (h1 >> 16) >= thr ? inv_keep : 0.f);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -26,6 +26,19 @@ __host__ __device__ inline int c0_round_stride(int W, int want_mod) {
   return rs;
 }
 
+// The image may arrive as the dataset's fp16 features (preprocessing/preprocess_images.py:39-53 stores them as float16;
+// the reference widens every sample on the host, data_preprocessing.py:167-176): xh != 0 reads __half NCHW rows and
+// widens them where the patch is staged -- exact, so results are bit-identical to a widened fp32 copy, without the
+// 0.15 GB read + 0.3 GB write + 0.3 GB re-read of a separate conversion pass per step.
+__device__ __forceinline__ float4 c0_load4(const void* x, int64_t e, int xh) {
+  if (xh) {
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    const h16x4 hv = *reinterpret_cast<const h16x4*>(static_cast<const uint16_t*>(x) + e);     // e % 4 == 0: 8-byte aligned
+    return make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+  }
+  return *reinterpret_cast<const float4*>(static_cast<const float*>(x) + e);
+}
+
 // ------------------------------------------------------------------ forward
 // grid (ceil(Hp/C0_FR), B); 256 threads; dynamic LDS = CI * C0_PR * RS floats (RS % 32 == 16).
 // A workgroup covers C0_FR pool rows (2*C0_FR + 2 image rows): with 4 rows the patch staging, the barrier and
@@ -37,7 +50,7 @@ constexpr int C0_PR = 2 * C0_FR + 2;
 
 // OB: 0 = pooled is stored as fp32, 1 = as bf16 (the bf16 path's P_0), 2 = x3-packed (the fp32x3 path: vqa_x3_pack's form)
 template <int CI, int TN, int OB>
-__global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const void* __restrict__ x, int xh, const float* __restrict__ w,
                                                         const float* __restrict__ bias, void* pooled_, uint8_t* amax,
                                                         int H, int W, int Hp, int Wp, int RS) {
   float* pooled = static_cast<float*>(pooled_);
@@ -52,10 +65,10 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restri
   // stage the planar patch: rows y0 .. y0+nrows-1 of every input channel; a wave takes whole rows
   for (int r = wave; r < CI * C0_PR; r += 4) {
     const int c = r / C0_PR, rr = r - c * C0_PR;        // wave-uniform
-    const float* src = x + ((int64_t)(b * CI + c) * H + y0 + rr) * W;
+    const int64_t src = ((int64_t)(b * CI + c) * H + y0 + rr) * W;
     float* dst = patch + c * plane + rr * RS;
     for (int c4 = lane; c4 < W / 4; c4 += 64) {
-      const float4 v = rr < nrows ? *reinterpret_cast<const float4*>(src + 4 * c4) : f4zero();
+      const float4 v = rr < nrows ? c0_load4(x, src + 4 * c4, xh) : f4zero();
       dst[4 * c4] = v.x; dst[4 * c4 + 1] = v.y; dst[4 * c4 + 2] = v.z; dst[4 * c4 + 3] = v.w;
     }
   }
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const float* __restri
 // C16: the pooled map is written channel-blocked, [B][Co/16][Hp][Wp][16] bf16 -- what the patch convolutions of the next
 // block cut their LDS patches from (csrc/conv_patch_bf16.hip); the arg-max bytes stay NHWC.
 template <int CI, int TN, bool C16 = false>
-__global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const void* __restrict__ x, int xh, const float* __restrict__ w,
                                                              const float* __restrict__ bias, uint16_t* pooled16,
                                                              uint8_t* amax, int H, int W, int Hp, int Wp, int RS) {
   extern __shared__ __attribute__((aligned(16))) float patch[];
@@ -147,10 +160,10 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __r
   const int plane = C0_PR * RS;
   for (int r = wave; r < CI * C0_PR; r += 4) {
     const int c = r / C0_PR, rr = r - c * C0_PR;
-    const float* src = x + ((int64_t)(b * CI + c) * H + y0 + rr) * W;
+    const int64_t src = ((int64_t)(b * CI + c) * H + y0 + rr) * W;
     float* dst = patch + c * plane + rr * RS;
     for (int c4 = lane; c4 < W / 4; c4 += 64) {
-      const float4 v = rr < nrows ? *reinterpret_cast<const float4*>(src + 4 * c4) : f4zero();
+      const float4 v = rr < nrows ? c0_load4(x, src + 4 * c4, xh) : f4zero();
       dst[4 * c4] = v.x; dst[4 * c4 + 1] = v.y; dst[4 * c4 + 2] = v.z; dst[4 * c4 + 3] = v.w;
     }
   }
@@ -208,9 +221,48 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __r
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[ks][j], ks == 0 ? zero : acc[j], 0, 0, 0);
     }
     const bool inner = 8 * t + 8 <= nwin;
+    if (C16) {
+      // C16 + wide stores: the tile's 8 windows x Co channels go through a wave-private LDS scratch behind the patch --
+      // pooled as [16-channel block][window][16] bf16, arg-max as [window][Co] bytes -- and leave as ONE 16-byte-per-lane
+      // store each (the element-wise form issued 8 two-byte and 8 one-byte store instructions per tile and was bound by that)
+      char* const scr = reinterpret_cast<char*>(patch) + CI * C0_PR * RS * 4 + wave * (8 * Co * 3);
+      char* const sam = scr + 8 * Co * 2;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float best = acc[j][4 * g];
+          int a = 0;
+          if (acc[j][4 * g + 1] > best) { best = acc[j][4 * g + 1]; a = 1; }
+          if (acc[j][4 * g + 2] > best) { best = acc[j][4 * g + 2]; a = 2; }
+          if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
+          best += bv[j];
+          const int win = 2 * g + h;
+          *reinterpret_cast<uint16_t*>(scr + (((2 * j + (l31 >> 4)) * 8 + win) * 16 + (l31 & 15)) * 2) = bf16_bits(best > 0.f ? best : 0.f);
+          *reinterpret_cast<uint8_t*>(sam + win * Co + 32 * j + l31) = best > 0.f ? (uint8_t)a : (uint8_t)4;
+        }
+      }
+      asm volatile("" ::: "memory");        // the wave's LDS accesses execute in order; keep the compiler's order as well
+      {
+        const int byte = lane * 16;          // pooled: 2 TN blocks x 8 windows x 32 bytes = 8 * Co * 2 bytes
+        if (byte < 8 * Co * 2) {
+          const int blk = byte >> 8, win = (byte & 255) >> 5, inrun = byte & 31;
+          const float4 v = *reinterpret_cast<const float4*>(scr + byte);
+          const bool ok = inner || 8 * t + win < nwin;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp,
+                                                 ok ? (int)(blk * plane16 * 2 + (8 * t + win) * 32 + inrun) : (int)BUF_OOB, 0, 0);
+        }
+        if (byte < 8 * Co) {                 // arg-max: 8 windows x Co bytes, contiguous in NHWC
+          const int win = byte / Co;
+          const float4 v = *reinterpret_cast<const float4*>(sam + byte);
+          const bool ok = inner || 8 * t + win < nwin;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ra, ok ? (int)(8 * t * Co + byte) : (int)BUF_OOB, 0, 0);
+        }
+      }
+      asm volatile("" ::: "memory");
+      continue;
+    }
     const uint32_t vl = (uint32_t)__mul24(8 * t + h, Co) + (uint32_t)l31;
-    // C16: element (window, channel 32 j + l31) lives at block (2 j + l31 / 16), window, l31 % 16
-    const uint32_t vl16 = (uint32_t)((l31 >> 4) * plane16 + (8 * t + h) * 16 + (l31 & 15));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const bool ok = inner || 8 * t + 2 * g + h < nwin;
@@ -223,8 +275,7 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __r
         if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
         best += bv[j];
         const uint32_t so = (uint32_t)(2 * g * Co + 32 * j);
-        if (C16) buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl16 : BUF_OOB, 2u * (uint32_t)(2 * j * plane16 + 2 * g * 16));
-        else buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl : BUF_OOB, 2u * so);
+        buf_store2(rp, bf16_bits(best > 0.f ? best : 0.f), ok ? 2u * vl : BUF_OOB, 2u * so);
         buf_store1(ra, best > 0.f ? (uint8_t)a : (uint8_t)4, ok ? vl : BUF_OOB, so);
       }
     }
@@ -234,7 +285,7 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const float* __r
 // ------------------------------------------------------------------ wgrad
 // persistent grid; 256 threads; LDS = CI*PLANE (x patch, 4 rows) + Wp*Co (dP row) floats + Wp*Co bytes (arg-max row)
 template <int CI, int TN>
-__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const void* __restrict__ x, int xh, const float* __restrict__ dp,
                                                           const uint8_t* __restrict__ am, float* slab, float* bias_slab,
                                                           int B, int H, int W, int Hp, int Wp, int RS, int PLANE) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -264,7 +315,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
       const int c4 = e % (W / 4);
       const int r = (e / (W / 4)) & 3;
       const int cc = e / (W / 4) / 4;
-      const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)(b * CI + cc) * H + 2 * py + r) * W + 4 * c4);
+      const float4 v = c0_load4(x, ((int64_t)(b * CI + cc) * H + 2 * py + r) * W + 4 * c4, xh);
       float* d = patch + cc * PLANE + r * RS + 4 * c4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -325,7 +376,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 // Persistent workgroups walk pooled rows; each wave keeps 32 x Co partial sums in accumulators for its whole life and
 // the four waves combine through LDS at the end: ONE slab per workgroup (deterministic, no atomics).
 template <int CI, int TN>
-__global__ __launch_bounds__(256) void conv0_wgrad_bf16_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dp,
+__global__ __launch_bounds__(256) void conv0_wgrad_bf16_kernel(const void* __restrict__ x, int xh, const uint16_t* __restrict__ dp,
                                                                const uint8_t* __restrict__ am, float* slab,
                                                                float* bias_slab, int B, int H, int W, int Hp, int Wp,
                                                                int RSTR, int NG) {
@@ -358,11 +409,11 @@ __global__ __launch_bounds__(256) void conv0_wgrad_bf16_kernel(const float* __re
       const int i = e % (2 * NG);                       // chunk of 8 positions
       const int r = (e / (2 * NG)) & 3;
       const int cc = e / (2 * NG) / 4;
-      const float* src = x + ((int64_t)(b * CI + cc) * H + 2 * py + r) * W + 8 * i;
+      const int64_t src = ((int64_t)(b * CI + cc) * H + 2 * py + r) * W + 8 * i;
       float v[12];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const float4 f = 8 * i + 4 * q < W ? *reinterpret_cast<const float4*>(src + 4 * q) : f4zero();   // W % 4 == 0
+        const float4 f = 8 * i + 4 * q < W ? c0_load4(x, src + 4 * q, xh) : f4zero();   // W % 4 == 0
         v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
       }
 #pragma unroll
@@ -483,11 +534,12 @@ extern "C" {
 
 int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride) { return c0_supported(Ci, H, W, Co, stride) ? 1 : 0; }
 
-int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, void* pooled, int pooled_is_bf16,
+int vqa_conv0_relu_pool_fwd(const void* x_nchw, int x_is_fp16, const float* w, const float* bias, void* pooled, int pooled_is_bf16,
                             uint8_t* argmax, int B, int Ci, int H, int W, int Co, vqa_stream_t stream) {
   VQA_REQUIRE(x_nchw && w && bias && pooled && argmax && B > 0, "vqa_conv0_relu_pool_fwd: bad args");
   VQA_REQUIRE(c0_supported(Ci, H, W, Co, 1), "vqa_conv0_relu_pool_fwd: unsupported shape Ci=%d H=%d W=%d Co=%d", Ci, H, W, Co);
   VQA_REQUIRE(((uintptr_t)x_nchw % 16) == 0, "vqa_conv0_relu_pool_fwd: input must be 16-byte aligned");
+  const int xh = x_is_fp16 ? 1 : 0;
   const int Hp = (H - 2) / 2, Wp = (W - 2) / 2, RS = c0_round_stride(W, 16);
   const size_t lds = (size_t)Ci * C0_PR * RS * 4;
   const dim3 grid((Hp + C0_FR - 1) / C0_FR, B);
@@ -496,7 +548,7 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
     auto kern = conv0_fwd_kernel<kCI, kTN, OB>;                                                                        \
     int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd)");                       \
     if (rc0) return rc0;                                                                                               \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, pooled, argmax, H, W, Hp, Wp, RS); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, xh, w, bias, pooled, argmax, H, W, Hp, Wp, RS); \
   })
   if (pooled_is_bf16 == 2 || pooled_is_bf16 == 4) {      // bf16 MFMA (image and weights rounded to bf16), bf16 output (4: C16)
     VQA_REQUIRE(Ci <= 3, "vqa_conv0_relu_pool_fwd: the bf16-MFMA first block needs Ci <= 3");
@@ -505,15 +557,16 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
       if constexpr (kCI <= 3) {
         if (pooled_is_bf16 == 4) {
           auto kern = conv0_fwd_bf16_kernel<kCI, kTN, true>;
-          int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd_bf16)");
+          const size_t lds16 = lds + (size_t)4 * 8 * Co * 3;       // + the four waves' epilogue scratch
+          int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds16, "attr(conv0_fwd_bf16 C16)");
           if (rc0) return rc0;
-          hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, static_cast<uint16_t*>(pooled),
+          hipLaunchKernelGGL(kern, grid, dim3(256), lds16, (hipStream_t)stream, x_nchw, xh, w, bias, static_cast<uint16_t*>(pooled),
                              argmax, H, W, Hp, Wp, RS);
         } else {
           auto kern = conv0_fwd_bf16_kernel<kCI, kTN, false>;
           int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd_bf16)");
           if (rc0) return rc0;
-          hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, w, bias, static_cast<uint16_t*>(pooled),
+          hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, xh, w, bias, static_cast<uint16_t*>(pooled),
                              argmax, H, W, Hp, Wp, RS);
         }
       }
@@ -525,7 +578,7 @@ int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bi
 
 int64_t vqa_conv0_wgrad_workspace_bytes(int Co) { return (int64_t)kC0Blocks * (32 + 1) * Co * 4; }
 
-int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B,
+int vqa_conv0_wgrad(const void* x_nchw, int x_is_fp16, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B,
                     int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes, vqa_stream_t stream) {
   VQA_REQUIRE(x_nchw && dpooled && argmax && dw && dbias && workspace, "vqa_conv0_wgrad: null pointer");
   VQA_REQUIRE(c0_supported(Ci, H, W, Co, 1), "vqa_conv0_wgrad: unsupported shape Ci=%d H=%d W=%d Co=%d", Ci, H, W, Co);
@@ -550,8 +603,8 @@ int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* ar
     auto kern = conv0_wgrad_kernel<kCI, kTN>;
     int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad)");
     if (rc0) return rc0;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, dpooled, argmax, slab, bias_slab, B, H, W, Hp, Wp,
-                       RS, PLANE);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, x_is_fp16 ? 1 : 0, dpooled, argmax, slab, bias_slab, B, H, W,
+                       Hp, Wp, RS, PLANE);
   });
   int rc = check_hip(hipGetLastError(), "conv0_wgrad launch");
   if (rc) return rc;
@@ -560,8 +613,8 @@ int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* ar
   return check_hip(hipGetLastError(), "conv0_wgrad_reduce launch");
 }
 
-int vqa_conv0_wgrad_bf16(const float* x_nchw, const void* dpooled_bf16, const uint8_t* argmax, float* dw, float* dbias,
-                         int B, int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes,
+int vqa_conv0_wgrad_bf16(const void* x_nchw, int x_is_fp16, const void* dpooled_bf16, const uint8_t* argmax, float* dw,
+                         float* dbias, int B, int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes,
                          vqa_stream_t stream) {
   VQA_REQUIRE(x_nchw && dpooled_bf16 && argmax && dw && dbias && workspace, "vqa_conv0_wgrad_bf16: null pointer");
   VQA_REQUIRE(c0_supported(Ci, H, W, Co, 1) && Ci <= 3, "vqa_conv0_wgrad_bf16: unsupported shape Ci=%d H=%d W=%d Co=%d", Ci, H, W, Co);
@@ -589,8 +642,8 @@ int vqa_conv0_wgrad_bf16(const float* x_nchw, const void* dpooled_bf16, const ui
       auto kern = conv0_wgrad_bf16_kernel<kCI, kTN>;
       int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad_bf16)");
       if (rc0) return rc0;
-      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, static_cast<const uint16_t*>(dpooled_bf16), argmax,
-                         slab, bias_slab, B, H, W, Hp, Wp, RSTR, NG);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, x_is_fp16 ? 1 : 0, static_cast<const uint16_t*>(dpooled_bf16),
+                         argmax, slab, bias_slab, B, H, W, Hp, Wp, RSTR, NG);
     }
   });
   int rc = check_hip(hipGetLastError(), "conv0_wgrad_bf16 launch");

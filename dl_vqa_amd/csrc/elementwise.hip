@@ -47,8 +47,8 @@ __global__ void dropout_add_kernel(const float* x, float* y, int64_t n, float p,
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 a = reinterpret_cast<const float4*>(x)[i];
     float4 b = reinterpret_cast<float4*>(y)[i];
-    b.x += a.x * drop_scale(seed, (uint64_t)(4 * i), p, inv_keep); b.y += a.y * drop_scale(seed, (uint64_t)(4 * i + 1), p, inv_keep);
-    b.z += a.z * drop_scale(seed, (uint64_t)(4 * i + 2), p, inv_keep); b.w += a.w * drop_scale(seed, (uint64_t)(4 * i + 3), p, inv_keep);
+    const float4 ds_ = drop_scale4(seed, (uint64_t)(4 * i), p, inv_keep);
+    b.x += a.x * ds_.x; b.y += a.y * ds_.y; b.z += a.z * ds_.z; b.w += a.w * ds_.w;
     reinterpret_cast<float4*>(y)[i] = b;
   }
   if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) {
@@ -74,8 +74,7 @@ __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, i
       float4 u = src[c];
       if (p > 0.f) {
         const uint64_t e = (uint64_t)r * C + 4 * c;
-        u.x *= drop_scale(seed, e, p, inv_keep); u.y *= drop_scale(seed, e + 1, p, inv_keep);
-        u.z *= drop_scale(seed, e + 2, p, inv_keep); u.w *= drop_scale(seed, e + 3, p, inv_keep);
+        { const float4 ds_ = drop_scale4(seed, e, p, inv_keep); u.x *= ds_.x; u.y *= ds_.y; u.z *= ds_.z; u.w *= ds_.w; }
       }
       ss += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
     }
@@ -88,8 +87,7 @@ __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, i
       float4 u = src[c];
       if (p > 0.f) {
         const uint64_t e = (uint64_t)r * C + 4 * c;
-        u.x *= drop_scale(seed, e, p, inv_keep); u.y *= drop_scale(seed, e + 1, p, inv_keep);
-        u.z *= drop_scale(seed, e + 2, p, inv_keep); u.w *= drop_scale(seed, e + 3, p, inv_keep);
+        { const float4 ds_ = drop_scale4(seed, e, p, inv_keep); u.x *= ds_.x; u.y *= ds_.y; u.z *= ds_.z; u.w *= ds_.w; }
       }
       const float4 o = make_float4(u.x * inv, u.y * inv, u.z * inv, u.w * inv);
       dst[c] = o;
@@ -97,8 +95,7 @@ __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, i
         const uint64_t e = (uint64_t)r * C + 4 * c;
         float4 d = o;
         if (p2 > 0.f) {
-          d.x *= drop_scale(seed2, e, p2, inv_keep2); d.y *= drop_scale(seed2, e + 1, p2, inv_keep2);
-          d.z *= drop_scale(seed2, e + 2, p2, inv_keep2); d.w *= drop_scale(seed2, e + 3, p2, inv_keep2);
+          { const float4 ds_ = drop_scale4(seed2, e, p2, inv_keep2); d.x *= ds_.x; d.y *= ds_.y; d.z *= ds_.z; d.w *= ds_.w; }
         }
         if (VB) {
           uint2 w;
@@ -136,8 +133,7 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
       float4 d = make_float4((a.x - b.x * k) * inv, (a.y - b.y * k) * inv, (a.z - b.z * k) * inv, (a.w - b.w * k) * inv);
       if (p > 0.f) {
         const uint64_t e = (uint64_t)r * C + 4 * c;
-        d.x *= drop_scale(seed, e, p, inv_keep); d.y *= drop_scale(seed, e + 1, p, inv_keep);
-        d.z *= drop_scale(seed, e + 2, p, inv_keep); d.w *= drop_scale(seed, e + 3, p, inv_keep);
+        { const float4 ds_ = drop_scale4(seed, e, p, inv_keep); d.x *= ds_.x; d.y *= ds_.y; d.z *= ds_.z; d.w *= ds_.w; }
       }
       dst[c] = d;
     }
@@ -288,8 +284,7 @@ __global__ void att_score_fwd_kernel(const void* xs, const float* wx, int wx_ld,
       float4 x = ld4<XB>(row, c);
       if (p > 0.f) {
         const uint64_t e = (uint64_t)m * xld + 4 * c;
-        x.x *= drop_scale(seed, e, p, inv_keep); x.y *= drop_scale(seed, e + 1, p, inv_keep);
-        x.z *= drop_scale(seed, e + 2, p, inv_keep); x.w *= drop_scale(seed, e + 3, p, inv_keep);
+        { const float4 ds_ = drop_scale4(seed, e, p, inv_keep); x.x *= ds_.x; x.y *= ds_.y; x.z *= ds_.z; x.w *= ds_.w; }
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -301,8 +296,7 @@ __global__ void att_score_fwd_kernel(const void* xs, const float* wx, int wx_ld,
         q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f);
         if (p > 0.f) {
           const uint64_t e = (uint64_t)m * xld + mid + 4 * c;
-          q.x *= drop_scale(seed, e, p, inv_keep); q.y *= drop_scale(seed, e + 1, p, inv_keep);
-          q.z *= drop_scale(seed, e + 2, p, inv_keep); q.w *= drop_scale(seed, e + 3, p, inv_keep);
+          { const float4 ds_ = drop_scale4(seed, e, p, inv_keep); q.x *= ds_.x; q.y *= ds_.y; q.z *= ds_.z; q.w *= ds_.w; }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -354,8 +348,7 @@ __global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int w
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
       if (p > 0.f) {
         const uint64_t e = (uint64_t)m * xld + 4 * c;
-        sc.x = drop_scale(seed, e, p, inv_keep); sc.y = drop_scale(seed, e + 1, p, inv_keep);
-        sc.z = drop_scale(seed, e + 2, p, inv_keep); sc.w = drop_scale(seed, e + 3, p, inv_keep);
+        sc = drop_scale4(seed, e, p, inv_keep);
       }
       float ds[G];
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -378,8 +371,7 @@ __global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int w
         float4 s2 = make_float4(1.f, 1.f, 1.f, 1.f);
         if (p > 0.f) {
           const uint64_t e = (uint64_t)m * xld + mid + 4 * c;
-          s2.x = drop_scale(seed, e, p, inv_keep); s2.y = drop_scale(seed, e + 1, p, inv_keep);
-          s2.z = drop_scale(seed, e + 2, p, inv_keep); s2.w = drop_scale(seed, e + 3, p, inv_keep);
+          s2 = drop_scale4(seed, e, p, inv_keep);
         }
         float4 t2 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

@@ -8,6 +8,9 @@
 
 #include <type_traits>
 #include "gemm_core.hpp"
+#include <map>
+#include <mutex>
+#include <utility>
 #include "gemm_epilogue.hpp"
 
 // This file is compiled six times (dl_vqa_amd/build.py): VQA_GEMM_PART = 0 is the host plumbing + the C ABI, parts 1-5 hold
@@ -35,6 +38,7 @@ int check_hip(hipError_t e, const char* what) {
 }
 
 // ------------------------------------------------------------------ launch plumbing
+constexpr int kMaxScratchPerLane = 256;   // bytes; the shipped kernels use 0-200 (tests/test_abi_cpu.py checks the code objects)
 static std::mutex g_attr_mu;
 static std::set<std::pair<int, const void*>> g_attr_done;
 int ensure_dyn_smem(const void* kernel, int bytes, const char* what) {
@@ -45,6 +49,20 @@ int ensure_dyn_smem(const void* kernel, int bytes, const char* what) {
   if (g_attr_done.count({dev, kernel})) return VQA_OK;
   rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
   if (rc) return rc;
+  // Private-segment guard (round-3 root cause of the round-2 hang): a workgroup-barrier kernel whose waves
+  // need scratch deadlocked once ~2 000 of its waves (512 bytes per lane: ~64 MB of scratch) were dispatched -- 176
+  // workgroups of 8 waves ran, 248 and more hung, whatever the problem shape; the same epilogue in a kernel with 100 bytes
+  // per lane ran at any grid.  Every kernel of this library meets at workgroup barriers, so a kernel that comes out of the
+  // compiler with a large private segment is refused here, before it can take a GPU down (VQA_ALLOW_SCRATCH=1: experiments).
+  hipFuncAttributes attr;
+  rc = check_hip(hipFuncGetAttributes(&attr, kernel), "hipFuncGetAttributes");
+  if (rc) return rc;
+  if (attr.localSizeBytes > kMaxScratchPerLane && !(getenv("VQA_ALLOW_SCRATCH") && atoi(getenv("VQA_ALLOW_SCRATCH")) == 1)) {
+    set_error("%s: the kernel needs %zu bytes of scratch per lane (limit %d): refused -- workgroup-barrier kernels with a "
+              "large private segment hang gfx950 beyond ~2000 resident waves (DESIGN.md 7(5))", what, (size_t)attr.localSizeBytes,
+              kMaxScratchPerLane);
+    return VQA_ERR_INVALID;
+  }
   g_attr_done.insert({dev, kernel});
   return VQA_OK;
 }
@@ -127,7 +145,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_persistent_
         int m0, n0;
         origin(t, m0, n0);
         gemm_epilogue<Cfg>(pe, acc, m0, n0, wm, wn, lane);
-      });
+      }
+#ifdef VQA_DIAG
+      , pe.bar_dbg
+#endif
+      );
 }
 
 template <class Cfg, class AL, class BL>
@@ -162,6 +184,31 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_kernel(type
 
 // ------------------------------------------------------------------ host side
 #if VQA_GEMM_PART == 0
+// Workgroups of `kernel` that are resident at once on the current device: min(planned, occupancy query) per CU x CUs.
+// Cached per (device, kernel).  <= 0: the query failed (vqa_last_error says why).
+int persistent_slots(const void* kernel, int threads, int smem_bytes, int planned_per_cu) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> cache;
+  int dev = 0;
+  if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return -1;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(dev, kernel);
+  const auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, cus = 0;
+  if (check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)smem_bytes),
+                "hipOccupancyMaxActiveBlocksPerMultiprocessor(gemm_persistent)"))
+    return -1;
+  if (check_hip(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute(CUs)")) return -1;
+  if (per_cu < 1) {
+    set_error("gemm_persistent: the kernel does not fit a CU (occupancy query says %d workgroups)", per_cu);
+    return -1;
+  }
+  const int slots = cus * (per_cu < planned_per_cu ? per_cu : planned_per_cu);
+  cache[key] = slots;
+  return slots;
+}
+
 GemmPlan plan_gemm(int M, int N, int K, int bk) {
   GemmPlan p;
   const int nk = (K + bk - 1) / bk;
@@ -208,6 +255,8 @@ GemmPlan plan_gemm(int M, int N, int K, int bk) {
 
 #endif  // VQA_GEMM_PART == 0
 
+int persistent_slots(const void* kernel, int threads, int smem_bytes, int planned_per_cu);
+
 template <class Cfg, class AL, class BL>
 int launch_gemm(const typename AL::Params& pa, const typename BL::Params& pb, const EpiParams& pe,
                        const GemmPlan& p, int K, hipStream_t s) {
@@ -223,7 +272,12 @@ int launch_gemm(const typename AL::Params& pa, const typename BL::Params& pb, co
       auto pk = gemm_persistent_kernel<Cfg, AL, BL>;
       int rc = ensure_dyn_smem(reinterpret_cast<const void*>(pk), SL::BYTES, "hipFuncSetAttribute(gemm_persistent)");
       if (rc) return rc;
-      const int slots = 256 * SL::WG_PER_CU;
+      // resident slots from the occupancy the runtime reports for THIS kernel (registers, scratch and LDS as compiled), not
+      // from the LDS layout alone: a variant that needs more registers than planned then gets a smaller grid instead of a
+      // second, queued round of workgroups.  (No workgroup ever waits for another one, so co-residency is a matter of
+      // speed here, never of progress.)
+      const int slots = persistent_slots(reinterpret_cast<const void*>(pk), Cfg::THREADS, SL::BYTES, SL::WG_PER_CU);
+      if (slots <= 0) return VQA_ERR_HIP;
       const int tiles = p.tiles_m * p.tiles_n;
       hipLaunchKernelGGL(pk, dim3(tiles < slots ? tiles : slots), dim3(Cfg::THREADS), SL::BYTES, s, pa, pb, pe,
                          p.tiles_m, p.tiles_n, p.nk, K, p.order);
@@ -285,10 +339,19 @@ VQA_GEMM_COMBOS(VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM_EXT, VQA_GEMM
 
 #if VQA_GEMM_PART == 0
 using namespace vqa;
+#ifdef VQA_DIAG
+static unsigned long long* g_bar_dbg = nullptr;
+#endif
 
 extern "C" {
 
 int vqa_abi_version(void) { return VQA_ABI_VERSION; }
+
+#ifdef VQA_DIAG
+/* diagnostic build only (tools/diag_barriers.py): device buffer of 4 x uint64 that the persistent GEMM kernels add their
+ * per-role barrier counts to ([0] loader-wave barriers, [1] loader waves, [2] MFMA-wave barriers, [3] MFMA waves) */
+int vqa_diag_barrier_buffer(void* dev_ptr) { g_bar_dbg = static_cast<unsigned long long*>(dev_ptr); return 0; }
+#endif
 const char* vqa_last_error(void) { return g_err; }
 
 int vqa_device_ok(void) {
@@ -372,6 +435,15 @@ int vqa_gemm(const float* A, int64_t lda, int transA, const float* B, int64_t ld
   hipStream_t s = (hipStream_t)stream;
   const GemmPlan p = plan_gemm(M, N, K);
   EpiParams pe{C, ldc, M, N, bias1, bias2, rowgroup, rg_ld, rg_div, rg_op, relu, accumulate, aux, nullptr, nullptr};
+#ifdef VQA_DIAG
+  pe.bar_dbg = g_bar_dbg;
+#endif
+#ifdef VQA_EXP_EPI_DROPOUT
+  {   // reconstruction of the withdrawn experiment: every row-group GEMM with ReLU drops 30 % in its epilogue
+    const bool on = rowgroup != nullptr && relu;
+    pe.drop_p = on ? 0.3f : 0.f; pe.drop_inv = 1.0f / 0.7f; pe.drop_seed = 0x1234567887654321ull;
+  }
+#endif
   if (p.splits > 1) {
     const int64_t need = (int64_t)p.splits * M * N * 4;
     if (!workspace || workspace_bytes < need) {

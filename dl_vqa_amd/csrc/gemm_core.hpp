@@ -601,9 +601,14 @@ __device__ __forceinline__ bool gemm_mainloop(Init&& init, Done&& done, f32x16 (
 // before the first issue() of a new tile.
 //   init_tile(tile, AL&, BL&)   : (re)initialise both loaders for a tile
 //   epilogue(tile, acc)         : MFMA waves only, no barriers inside
+// Barrier protocol (the invariant a workgroup's life depends on): BOTH roles execute exactly 1 + my_tiles * nk workgroup
+// barriers -- the loader waves one after the prologue and one per stored stage, the MFMA waves one before the first stage
+// and one per computed stage -- on paths that share no code.  A -DVQA_DIAG build counts them per role (bar_dbg) and
+// tools/diag_barriers.py asserts the two averages are equal after a run.
 template <class Cfg, class AL, class BL, bool SHORT_TAIL, class InitTile, class Epilogue>
 __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntiles, int nk, int Ktot, float* smem,
-                                                InitTile&& init_tile, Epilogue&& epilogue) {
+                                                InitTile&& init_tile, Epilogue&& epilogue,
+                                                unsigned long long* bar_dbg = nullptr) {
   using SL = SmemLayout<Cfg, AL::kTypeR, BL::kTypeR>;
   constexpr int D = Cfg::PREFETCH;
   if (first >= ntiles) return;
@@ -637,6 +642,9 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
 #pragma unroll
     for (int d = 0; d < D; ++d) next(rawA[d], rawB[d]);
     __syncthreads();
+#ifdef VQA_DIAG
+    unsigned long long nbar = 1;
+#endif
     for (int s = 0; s < total; s += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -646,9 +654,15 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
           stage_store_one<Cfg, BL, false>(bl, rawB[d], Bs0 + nxt * SL::BBUF, ltid);
           next(rawA[d], rawB[d]);
           __syncthreads();
+#ifdef VQA_DIAG
+          ++nbar;
+#endif
         }
       }
     }
+#ifdef VQA_DIAG
+    if (bar_dbg && (threadIdx.x & 63) == 0) { atomicAdd(bar_dbg + 0, nbar); atomicAdd(bar_dbg + 1, 1ull); }
+#endif
     return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -657,6 +671,9 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
   const float* const Bs0 = smem + 2 * SL::ABUF;
   __builtin_amdgcn_s_setprio(VQA_PRIO_MFMA);
   __syncthreads();
+#ifdef VQA_DIAG
+  unsigned long long nbar = 1;
+#endif
   int s = 0;
   for (int tile = first; tile < ntiles; tile += stride) {
     f32x16 acc[Cfg::TM][Cfg::TN];
@@ -672,9 +689,15 @@ __device__ __forceinline__ void gemm_persistent(int first, int stride, int ntile
       if (SHORT_TAIL && Ktot - ks * BK <= 8) mma_steps<Cfg, AL::kTypeR, BL::kTypeR, 1>(Ac, Bc, acc, wm, wn, lane);
       else mma_steps<Cfg, AL::kTypeR, BL::kTypeR, 4>(Ac, Bc, acc, wm, wn, lane);
       __syncthreads();
+#ifdef VQA_DIAG
+      ++nbar;
+#endif
     }
     epilogue(tile, acc);
   }
+#ifdef VQA_DIAG
+  if (bar_dbg && lane == 0) { atomicAdd(bar_dbg + 2, nbar); atomicAdd(bar_dbg + 3, 1ull); }
+#endif
 }
 
 template <class Cfg>

@@ -14,6 +14,14 @@ struct EpiParams {
   float* aux;   // optional: raw product before the epilogue, same shape/ld as C
   float* slab;  // != nullptr: split-K partials [split][M][N]
   uint16_t* Cb; // != nullptr: the result is stored as bf16 here (same ldc, in elements) instead of fp32 in C
+#ifdef VQA_DIAG
+  unsigned long long* bar_dbg;   // diagnostic build: [0] barriers executed by loader waves, [1] loader waves, [2] / [3] the same for MFMA waves
+#endif
+#ifdef VQA_EXP_EPI_DROPOUT
+  // Reconstruction of the round-2 experiment that was withdrawn after a hang (tools/build_variant.sh hangrepro
+  // -DVQA_EXP_EPI_DROPOUT): dropout of the attention branch inside the GEMM epilogue.  Never part of the shipped library.
+  float drop_p; float drop_inv; uint64_t drop_seed;
+#endif
 };
 
 __device__ __forceinline__ uint16_t epi_bf16(float x) {       // round to nearest even (v_cvt_pk_bf16_f32)
@@ -111,6 +119,10 @@ __device__ __forceinline__ void gemm_epilogue_mode(const EpiParams& pe, f32x16 (
           v += cb;
           if (relu) v = fmaxf(v, 0.f);
           if (accum) v += old[r];
+#ifdef VQA_EXP_EPI_DROPOUT
+          if (pe.drop_p > 0.f)
+            v *= drop_scale(pe.drop_seed, (uint64_t)(row0 + dr) * (uint64_t)pe.N + (uint64_t)col, pe.drop_p, pe.drop_inv);
+#endif
           if (ob) {
             const uint32_t o = vo(dr);
             __builtin_amdgcn_raw_buffer_store_b16(epi_bf16(v), rb, (int)(o == BUF_OOB ? BUF_OOB : o >> 1),
@@ -138,6 +150,62 @@ __device__ __forceinline__ void gemm_epilogue(const EpiParams& pe, f32x16 (&acc)
   if (rg == 1) return gemm_epilogue_mode<Cfg, 1, true, true>(pe, acc, m0, n0, wm, wn, lane);
   if (rg == 2) return gemm_epilogue_mode<Cfg, 2, true, true>(pe, acc, m0, n0, wm, wn, lane);
   return gemm_epilogue_mode<Cfg, 0, true, true>(pe, acc, m0, n0, wm, wn, lane);
+}
+
+// bf16 result through LDS: the direct form above issues one 2-byte store per accumulator register (64 store instructions of
+// 128 bytes per wave and tile): for the v_conv forward of the bf16 path -- 3 GB of x = relu(v' + q') per step -- that was
+// store-ISSUE bound at ~1.1 TB/s.  Here an MFMA wave writes its WM x WN block as bf16 into a wave-private LDS scratch
+// (the stage buffers are free: the last K-step barrier has passed and the loader waves have exited) and stores it with
+// 16 bytes per lane, whole 128-byte runs of a row.  Interior tiles without aux / accumulate only (uniform test by the caller).
+template <class Cfg>
+__device__ __forceinline__ void gemm_epilogue_bf16_staged(const EpiParams& pe, f32x16 (&acc)[Cfg::TM][Cfg::TN], int m0, int n0,
+                                                          int wm, int wn, int lane, float* smem) {
+  static_assert(Cfg::WN == 64, "64-column wave blocks: a row of the scratch is one 128-byte run");
+  constexpr int PITCH = 128;                                           // bytes per scratch row (64 bf16)
+  char* const scr = reinterpret_cast<char*>(smem) + (wm * Cfg::WAVES_N + wn) * (Cfg::WM * PITCH);
+  const int RG = !pe.rg ? 0 : 1;
+  const int g0 = RG ? m0 / pe.rg_div : 0;
+  const int boundary = (g0 + 1) * pe.rg_div;
+  const bool mul = pe.rg_op != 0, relu = pe.relu != 0;
+  const bool one_group = RG == 1 && boundary >= m0 + Cfg::BM;
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < Cfg::TN; ++j) {
+    const int col = n0 + wn * Cfg::WN + 32 * j + l31;
+    float cb = 0.f;
+    if (pe.bias1) cb += pe.bias1[col];
+    if (pe.bias2) cb += pe.bias2[col];
+    float rg0 = 0.f, rg1 = 0.f;
+    if (RG == 1) {
+      rg0 = pe.rg[(int64_t)g0 * pe.rg_ld + col];
+      rg1 = (!one_group && boundary < pe.M) ? pe.rg[(int64_t)(g0 + 1) * pe.rg_ld + col] : rg0;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) {
+      const int row0 = m0 + wm * Cfg::WM + 32 * i + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r];
+        if (RG) {
+          const float t = (one_group || row0 + dr < boundary) ? rg0 : rg1;
+          v = mul ? v * t : v + t;
+        }
+        v += cb;
+        if (relu) v = fmaxf(v, 0.f);
+        *reinterpret_cast<uint16_t*>(scr + (32 * i + 4 * h + dr) * PITCH + (32 * j + l31) * 2) = epi_bf16(v);
+      }
+    }
+  }
+  asm volatile("" ::: "memory");     // the wave's LDS accesses execute in order; keep the compiler's order as well
+  const __amdgpu_buffer_rsrc_t ro = buf_rsrc(pe.Cb + (int64_t)(m0 + wm * Cfg::WM) * pe.ldc + n0 + wn * Cfg::WN);
+#pragma unroll
+  for (int q = 0; q < Cfg::WM * PITCH / 1024; ++q) {
+    const int byte = q * 1024 + lane * 16;
+    const int row = byte / PITCH, inrow = byte % PITCH;
+    const float4 v = *reinterpret_cast<const float4*>(scr + byte);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)((uint32_t)row * (uint32_t)pe.ldc * 2u + inrow), 0, 0);
+  }
 }
 
 static __global__ void splitk_reduce_kernel(EpiParams pe, int splits) {

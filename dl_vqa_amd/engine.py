@@ -71,6 +71,10 @@ class Engine:
         self.bf16 = compute_dtype == "bf16"
         self.x3 = compute_dtype == "fp32x3"
         self.x3_gemm = self.x3 and os.environ.get("VQA_X3_GEMM", "1") != "0"     # diagnostic switch, read once
+        # bf16 path: q_lin / lin1 / lin2 on bf16 MFMA too (BASELINE configs[3] "bf16 conv/FC") when every dimension is a multiple
+        # of 8 (16-byte operand rows); VQA_FC16=0 keeps them on the fp32 GEMM
+        self.fc16 = (self.bf16 and os.environ.get("VQA_FC16", "1") != "0"
+                     and all(d % 8 == 0 for d in (self.Q, self.mid, self.Dc, self.hid, self.A)))
         if self.bf16:
             if self.L < 2 or any(ch % 64 for ch in self.channels[1:]) or self.mid % 8 or self.stride != 1:
                 raise ValueError("the bf16 path needs >= 2 conv blocks, stride 1 and channel counts that are multiples "
@@ -87,6 +91,18 @@ class Engine:
                 return False
             h, w = ops.conv_out_hw(h, w, 1)
         return True
+
+    @staticmethod
+    def _rows16(x: Tensor, ld: int, rows: int, cols: int, rows8: int) -> Tensor:
+        """bf16 copy [rows8, cols] of the fp32 matrix x (leading dimension ld), rows beyond `rows` zero."""
+        if ld != cols or not x.is_contiguous():
+            t = torch.empty(rows, cols, dtype=torch.float32, device=x.device)
+            ops.add2d(x, ld, None, 0, t, cols, rows, cols)
+            x = t
+        out = torch.zeros(rows8, cols, dtype=torch.bfloat16, device=x.device) if rows8 != rows else \
+            torch.empty(rows, cols, dtype=torch.bfloat16, device=x.device)
+        ops.to_bf16(x.view(rows, cols), out=out[:rows])
+        return out
 
     def _x3_layer(self, x_shape, Co) -> bool:
         """fp32x3 mode: does this conv block (NHWC input shape, output channels) run on the split kernels?"""
@@ -163,7 +179,8 @@ class Engine:
 
     def _forward(self, P: Dict[str, Tensor], v: Tensor, q: Tensor, q_len: Tensor, training: bool, seed: int,
                  keep: bool, bad_tokens: Optional[Tensor] = None):
-        assert v.is_cuda and v.dtype == torch.float32 and v.dim() == 4, "v must be a float32 CUDA tensor [B,C,S,S]"
+        assert v.is_cuda and v.dtype in (torch.float32, torch.float16) and v.dim() == 4, \
+            "v must be a float32 (or the dataset's float16) CUDA tensor [B,C,S,S]"
         v = v.contiguous()
         q = q.to(device=v.device, dtype=torch.int64).contiguous()
         q_len = q_len.to(device=v.device, dtype=torch.int64).contiguous()
@@ -229,6 +246,10 @@ class Engine:
         # the first block has a dedicated kernel that reads the NCHW image as is (K = 27 is too thin for the
         # generic implicit GEMM); otherwise the image is converted to NHWC4 once
         fast0 = ops.conv0_supported(v.shape[1], v.shape[2], v.shape[3], self.channels[1], self.stride)
+        if v.dtype == torch.float16 and not fast0:
+            # the dedicated first-block kernels read the dataset's fp16 features as they are (widened where the LDS patch is
+            # staged); only shapes they do not cover take a widened copy through the generic NHWC path
+            v = ops.half_to_float(v)
         acts = [v if fast0 else ops.nchw_to_nhwc4(v)]
         idxs, wds = [], []
         # bf16 path: blocks 1.. on the patch convolutions (csrc/conv_patch_bf16.hip: LDS-resident input patch, activations
@@ -312,7 +333,18 @@ class Engine:
         else:
             q_in, ld_q = qf, Dc
         qp = new(B, mid)
-        ops.gemm(q_in, P["attention.q_lin.weight"], qp, B, mid, Q, lda=ld_q, bias1=P["attention.q_lin.bias"], tag=20)
+        fc = None
+        if self.fc16:
+            # bf16 FC: activations and weights rounded to bf16 where the GEMM stages them (rows padded to a multiple of 8 with
+            # zeros: they become the K dimension of the weight-gradient products), fp32 accumulation, fp32 outputs
+            B8 = (B + 7) // 8 * 8
+            fc = SimpleNamespace(B8=B8,
+                                 wq=ops.to_bf16(P["attention.q_lin.weight"]), w1=ops.to_bf16(P["classifier.lin1.weight"]),
+                                 w2=ops.to_bf16(P["classifier.lin2.weight"]))
+            fc.q16 = self._rows16(q_in, ld_q, B, Q, B8)
+            ops.gemm_bf16(fc.q16, fc.wq, qp, B, mid, Q, bias1=P["attention.q_lin.bias"], tag=20)
+        else:
+            ops.gemm(q_in, P["attention.q_lin.weight"], qp, B, mid, Q, lda=ld_q, bias1=P["attention.q_lin.bias"], tag=20)
         # x = relu(v' + q') | relu(v' * q') | relu(cat[v', q'])  (model.py:188-193); v' itself is only kept for
         # '*' (its backward needs it), as the aux output of the same GEMM
         # (bf16 path: x is stored as bf16 -- it is streamed three more times and becomes, overwritten in place by
@@ -336,16 +368,23 @@ class Engine:
         p_cls = self.p_cls if tr else 0.0
         c_in = ops.dropout(combined, p_cls, sd(SITE_CLS1)) if p_cls > 0 else combined
         h1 = new(B, hid)
-        ops.gemm(c_in, P["classifier.lin1.weight"], h1, B, hid, Dc, bias1=P["classifier.lin1.bias"], relu=True, tag=30)
-        h1d = ops.dropout(h1, p_cls, sd(SITE_CLS2)) if p_cls > 0 else h1
         logits = new(B, A)
-        ops.gemm(h1d, P["classifier.lin2.weight"], logits, B, A, hid, bias1=P["classifier.lin2.bias"], tag=31)
+        if fc is not None:
+            fc.c16 = self._rows16(c_in, Dc, B, Dc, fc.B8)
+            ops.gemm_bf16(fc.c16, fc.w1, h1, B, hid, Dc, bias1=P["classifier.lin1.bias"], relu=True, tag=30)
+            h1d = ops.dropout(h1, p_cls, sd(SITE_CLS2)) if p_cls > 0 else h1
+            fc.h16 = self._rows16(h1d, hid, B, hid, fc.B8)
+            ops.gemm_bf16(fc.h16, fc.w2, logits, B, A, hid, bias1=P["classifier.lin2.bias"], tag=31)
+        else:
+            ops.gemm(c_in, P["classifier.lin1.weight"], h1, B, hid, Dc, bias1=P["classifier.lin1.bias"], relu=True, tag=30)
+            h1d = ops.dropout(h1, p_cls, sd(SITE_CLS2)) if p_cls > 0 else h1
+            ops.gemm(h1d, P["classifier.lin2.weight"], logits, B, A, hid, bias1=P["classifier.lin2.bias"], tag=31)
 
         if not keep:
             return logits, None
         ctx = SimpleNamespace(B=B, T=T, Pn=Pn, q=q, q_len=q_len, acts=acts, idxs=idxs, wds=wds, vn=vn, norm=norm,
                               x_emb=x_emb, lstm=lstm, v_in=v_in, v16=v16, wv16=wv16, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
-                              c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, use_pc=use_pc, vprime=vprime, qp=qp, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
+                              c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, use_pc=use_pc, fc=fc, vprime=vprime, qp=qp, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
                               seed=seed, stages=dict(pooled=pooled, score=score, combined=combined))
         return logits, ctx
 
@@ -376,17 +415,31 @@ class Engine:
             dlogits = dl
 
         # ---- classifier
-        ops.gemm(dlogits, ctx.h1d, Gr["classifier.lin2.weight"], A, hid, B, transA=True, transB=False, lda=ldA,
-                 ldb=hid, tag=40)
-        ops.colsum(dlogits, B, A, Gr["classifier.lin2.bias"], ld=ldA)
+        fc = ctx.fc
         dh1 = new(B, hid)
-        ops.gemm(dlogits, P["classifier.lin2.weight"], dh1, B, hid, A, transB=False, lda=ldA, ldb=hid, tag=41)
-        ops.relu_drop_bwd(ctx.h1, dh1, dh1, ctx.p_cls, sd(SITE_CLS2))
-        ops.gemm(dh1, ctx.c_in, Gr["classifier.lin1.weight"], hid, Dc, B, transA=True, transB=False, lda=hid, ldb=Dc,
-                 tag=42)
-        ops.colsum(dh1, B, hid, Gr["classifier.lin1.bias"])
         dcomb = new(B, Dc)
-        ops.gemm(dh1, P["classifier.lin1.weight"], dcomb, B, Dc, hid, transB=False, lda=hid, ldb=Dc, tag=43)
+        if fc is not None:      # bf16 FC: output gradients staged as bf16 (zero rows up to B8: the K of the dW products)
+            dl16 = self._rows16(dlogits, ldA, B, A, fc.B8)
+            ops.gemm_bf16(dl16, fc.h16, Gr["classifier.lin2.weight"], A, hid, fc.B8, transA=True, transB=False, lda=A,
+                          ldb=hid, tag=40)
+            ops.colsum(dlogits, B, A, Gr["classifier.lin2.bias"], ld=ldA)
+            ops.gemm_bf16(dl16, fc.w2, dh1, B, hid, A, transB=False, lda=A, ldb=hid, tag=41)
+            ops.relu_drop_bwd(ctx.h1, dh1, dh1, ctx.p_cls, sd(SITE_CLS2))
+            dh16 = self._rows16(dh1, hid, B, hid, fc.B8)
+            ops.gemm_bf16(dh16, fc.c16, Gr["classifier.lin1.weight"], hid, Dc, fc.B8, transA=True, transB=False, lda=hid,
+                          ldb=Dc, tag=42)
+            ops.colsum(dh1, B, hid, Gr["classifier.lin1.bias"])
+            ops.gemm_bf16(dh16, fc.w1, dcomb, B, Dc, hid, transB=False, lda=hid, ldb=Dc, tag=43)
+        else:
+            ops.gemm(dlogits, ctx.h1d, Gr["classifier.lin2.weight"], A, hid, B, transA=True, transB=False, lda=ldA,
+                     ldb=hid, tag=40)
+            ops.colsum(dlogits, B, A, Gr["classifier.lin2.bias"], ld=ldA)
+            ops.gemm(dlogits, P["classifier.lin2.weight"], dh1, B, hid, A, transB=False, lda=ldA, ldb=hid, tag=41)
+            ops.relu_drop_bwd(ctx.h1, dh1, dh1, ctx.p_cls, sd(SITE_CLS2))
+            ops.gemm(dh1, ctx.c_in, Gr["classifier.lin1.weight"], hid, Dc, B, transA=True, transB=False, lda=hid, ldb=Dc,
+                     tag=42)
+            ops.colsum(dh1, B, hid, Gr["classifier.lin1.bias"])
+            ops.gemm(dh1, P["classifier.lin1.weight"], dcomb, B, Dc, hid, transB=False, lda=hid, ldb=Dc, tag=43)
         if ctx.p_cls > 0:
             ops.dropout(dcomb, ctx.p_cls, sd(SITE_CLS1), out=dcomb)
         ready("classifier")
@@ -426,17 +479,27 @@ class Engine:
                 ops.dropout_add(dv_in, dvn, ctx.p_att, sd(SITE_ATT_V))
             else:
                 ops.gemm(dxpre, wv, dvn, B * Pn, C, mid, transB=False, lda=mid, ldb=C, accumulate=True, tag=45, x3=gx3)
-        ops.gemm(dqp, ctx.q_in, Gr["attention.q_lin.weight"], mid, Q, B, transA=True, transB=False, lda=mid,
-                 ldb=ctx.ld_q, tag=46)
         ops.colsum(dqp, B, mid, Gr["attention.q_lin.bias"])
         wq = P["attention.q_lin.weight"]
-        if ctx.p_att > 0:
+        if fc is not None:
+            dqp16 = self._rows16(dqp, mid, B, mid, fc.B8)
+            ops.gemm_bf16(dqp16, fc.q16, Gr["attention.q_lin.weight"], mid, Q, fc.B8, transA=True, transB=False, lda=mid,
+                          ldb=Q, tag=46)
             dq_in = new(B, Q)
-            ops.gemm(dqp, wq, dq_in, B, Q, mid, transB=False, lda=mid, ldb=Q, tag=47)
-            ops.dropout(dq_in, ctx.p_att, sd(SITE_ATT_Q), out=dq_in)
+            ops.gemm_bf16(dqp16, fc.wq, dq_in, B, Q, mid, transB=False, lda=mid, ldb=Q, tag=47)
+            if ctx.p_att > 0:
+                ops.dropout(dq_in, ctx.p_att, sd(SITE_ATT_Q), out=dq_in)
             ops.add2d(dcomb[:, GC:], Dc, dq_in, Q, dcomb[:, GC:], Dc, B, Q)
         else:
-            ops.gemm(dqp, wq, dcomb[:, GC:], B, Q, mid, transB=False, lda=mid, ldb=Q, ldc=Dc, accumulate=True, tag=47)
+            ops.gemm(dqp, ctx.q_in, Gr["attention.q_lin.weight"], mid, Q, B, transA=True, transB=False, lda=mid,
+                     ldb=ctx.ld_q, tag=46)
+            if ctx.p_att > 0:
+                dq_in = new(B, Q)
+                ops.gemm(dqp, wq, dq_in, B, Q, mid, transB=False, lda=mid, ldb=Q, tag=47)
+                ops.dropout(dq_in, ctx.p_att, sd(SITE_ATT_Q), out=dq_in)
+                ops.add2d(dcomb[:, GC:], Dc, dq_in, Q, dcomb[:, GC:], Dc, B, Q)
+            else:
+                ops.gemm(dqp, wq, dcomb[:, GC:], B, Q, mid, transB=False, lda=mid, ldb=Q, ldc=Dc, accumulate=True, tag=47)
         ready("attention")
 
         # ---- LSTM (BPTT over the masked steps), embedding

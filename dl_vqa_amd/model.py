@@ -312,10 +312,10 @@ class VqaNet(nn.Module):
         if not v.is_cuda:
             raise RuntimeError("dl_vqa_amd.VqaNet.forward needs CUDA (HIP) tensors; there is no CPU fallback")
         self._validate_tokens(q)
-        if v.dtype == torch.float16:
-            # the dataset's storage format (preprocessing/preprocess_images.py:39-53): widen on the device
-            from . import ops
-            v = ops.half_to_float(v.contiguous())
+        # v may be the dataset's fp16 storage format (preprocessing/preprocess_images.py:39-53): the first-block kernels read
+        # it as it is (engine.py); no widened copy is made
+        if v.dtype not in (torch.float32, torch.float16):
+            v = v.float()
         seed = self._next_seed() if self.training else 0
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._params)
         if need_grad:

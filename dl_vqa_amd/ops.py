@@ -184,7 +184,9 @@ def conv0_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dty
               torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x_nchw.device))
     amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x_nchw.device)
     mode = 3 if out_packed else (4 if out_c16 else 2 if bf16_mfma else 1) if out_dtype == torch.bfloat16 else 0
-    call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(pooled), mode, ptr(amax), B, Ci, H, W, Co, stream())
+    assert x_nchw.dtype in (torch.float32, torch.float16) and x_nchw.is_contiguous()
+    call("vqa_conv0_relu_pool_fwd", ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(w), ptr(bias), ptr(pooled), mode,
+         ptr(amax), B, Ci, H, W, Co, stream())
     return pooled, amax
 
 
@@ -193,7 +195,7 @@ def conv0_wgrad(x_nchw, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor):
     B, Ci, H, W = x_nchw.shape
     Co = dw.shape[0]
     ws = workspace(lib.vqa_conv0_wgrad_workspace_bytes(Co), x_nchw.device)
-    call("vqa_conv0_wgrad", ptr(x_nchw), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, Ci, H, W, Co, ptr(ws),
+    call("vqa_conv0_wgrad", ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, Ci, H, W, Co, ptr(ws),
          ws.numel() * 4, stream())
 
 
@@ -204,7 +206,7 @@ def conv0_wgrad_bf16(x_nchw, dpooled16, amax, dw: torch.Tensor, dbias: torch.Ten
     B, Ci, H, W = x_nchw.shape
     Co = dw.shape[0]
     ws = workspace(lib.vqa_conv0_wgrad_workspace_bytes(Co), x_nchw.device)
-    call("vqa_conv0_wgrad_bf16", ptr(x_nchw), ptr(dpooled16), ptr(amax), ptr(dw), ptr(dbias), B, Ci, H, W, Co, ptr(ws),
+    call("vqa_conv0_wgrad_bf16", ptr(x_nchw), int(x_nchw.dtype == torch.float16), ptr(dpooled16), ptr(amax), ptr(dw), ptr(dbias), B, Ci, H, W, Co, ptr(ws),
          ws.numel() * 4, stream())
 
 

@@ -85,7 +85,7 @@ def run_batch(model, log_softmax, batch_data, max_answers, batch_divisor: Option
     a_values = a_values.to(dev, non_blocking=True)
     q_len = q_len.to(dev, non_blocking=True)
     # the dataset stores fp16 features (data_preprocessing.py:174 casts them on the host, per sample): the fp16
-    # batch goes over PCIe as is and VqaNet.forward widens it on the device (vqa_half_to_float)
+    # batch goes over PCIe as is and the first-block kernels read it as it is (widened where their LDS patch is staged)
     if v.dtype not in (torch.float32, torch.float16):
         v = v.float()
     y_hat = model(v, q, q_len)

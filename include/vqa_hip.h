@@ -118,20 +118,21 @@ int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argma
  * NCHW image directly (no layout conversion), weights/bias in torch layout, same pooled/argmax outputs
  * as vqa_conv3x3_relu_pool_fwd.  vqa_conv0_supported() tells whether a shape takes this path. */
 int vqa_conv0_supported(int Ci, int H, int W, int Co, int stride);
-int vqa_conv0_relu_pool_fwd(const float* x_nchw, const float* w, const float* bias, void* pooled,
+int vqa_conv0_relu_pool_fwd(const void* x_nchw, int x_is_fp16 /* 1: __half NCHW as the dataset stores it, widened where
+                            the patch is staged (preprocess_images.py:39-53); 0: float */, const float* w, const float* bias, void* pooled,
                             int pooled_is_bf16 /* 0: fp32 out; 1: fp32 MFMA, P_0 stored as bf16; 2 (bf16 path):
                             image and weights rounded to bf16, two 32x32x16 bf16 MFMA k-steps, bf16 out; 3 (fp32x3 path): fp32
                             MFMA, the output written x3-packed (vqa_x3_pack's form, 6 bytes per element); 4: as 2 with the
                             pooled map channel-blocked, [B][Co/16][Hp][Wp][16] (what vqa_pconv_* read; arg-max stays NHWC) */, uint8_t* argmax, int B, int Ci,
                             int H, int W, int Co, vqa_stream_t stream);
 int64_t vqa_conv0_wgrad_workspace_bytes(int Co);
-int vqa_conv0_wgrad(const float* x_nchw, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias,
+int vqa_conv0_wgrad(const void* x_nchw, int x_is_fp16, const float* dpooled, const uint8_t* argmax, float* dw, float* dbias,
                     int B, int Ci, int H, int W, int Co, float* workspace, int64_t workspace_bytes,
                     vqa_stream_t stream);
 
 /* bf16 path: the first block's weight gradient on bf16 MFMA (image rounded to bf16 where it is staged, bf16 pooled
  * gradient as written by vqa_conv3x3_dgrad_bf16, fp32 accumulation, fp32 dw / dbias).  Same workspace query. */
-int vqa_conv0_wgrad_bf16(const float* x_nchw, const void* dpooled_bf16, const uint8_t* argmax, float* dw,
+int vqa_conv0_wgrad_bf16(const void* x_nchw, int x_is_fp16, const void* dpooled_bf16, const uint8_t* argmax, float* dw,
                          float* dbias, int B, int Ci, int H, int W, int Co, float* workspace,
                          int64_t workspace_bytes, vqa_stream_t stream);
 

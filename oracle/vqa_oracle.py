@@ -61,7 +61,9 @@ def _drop(x: Tensor, masks: Optional[dict], site: str) -> Tensor:
 # bf16 path (BASELINE configs[3]): the same oracle with the operands of the re-typed contractions rounded to
 # bfloat16 where the HIP path stores / stages them as bf16 (round to nearest even; products of two bf16 values are
 # exact in fp32, accumulation stays fp32): the image and the activations between conv blocks, the conv weights, the
-# v_conv input and weight; in backward, the gradients the HIP path stores as bf16 (dP of the conv blocks >= 1, dx').
+# v_conv input and weight, the inputs and weights of q_lin / lin1 / lin2 (when their dimensions allow: fc16_dims_ok); in
+# backward, the gradients the HIP path stores as bf16 (dP of the conv blocks >= 1, dx') or stages as bf16 (the output
+# gradients of the three linear layers).
 def rb(x: Tensor) -> Tensor:
     return x.to(torch.bfloat16).to(x.dtype)
 
@@ -103,6 +105,21 @@ def _rfb(x: Tensor, fwd: bool, bwd: bool, on: bool) -> Tensor:
 def _w16(w: Tensor, on: bool) -> Tensor:
     """bf16 copy of an fp32 master weight (straight-through: the gradient goes to the master weight unchanged)"""
     return w + (rb(w) - w).detach() if on else w
+
+
+def fc16_dims_ok(sd: Dict[str, Tensor]) -> bool:
+    """bf16 path: q_lin / lin1 / lin2 run on bf16 MFMA when every one of their dimensions is a multiple of 8 (the bf16 GEMM's
+    16-byte operand rows); the same rule as dl_vqa_amd.engine.Engine.fc16."""
+    dims = list(sd["attention.q_lin.weight"].shape) + list(sd["classifier.lin1.weight"].shape) + \
+        list(sd["classifier.lin2.weight"].shape)
+    return all(int(d) % 8 == 0 for d in dims)
+
+
+def _linear16(x: Tensor, w: Tensor, b: Tensor, on: bool) -> Tensor:
+    """nn.Linear on the bf16 path: input and weight rounded to bf16 where the GEMM stages them, fp32 accumulation and fp32
+    output; in backward the output gradient is rounded to bf16 before both products (dW = dy^T x, dx = dy W)."""
+    y = F.linear(_rfb(x, fwd=True, bwd=False, on=on), _w16(w, on))
+    return _rfb(y, fwd=False, bwd=True, on=on) + b          # the bias gradient is the fp32 column sum of the unrounded dy
 
 
 def image_encoder(sd: Dict[str, Tensor], v: Tensor, stride: int = 1,
@@ -190,7 +207,8 @@ def attention_scores(sd: Dict[str, Tensor], v: Tensor, q: Tensor, do_option: str
     wv = _w16(sd["attention.v_conv.weight"], bf16)          # [mid, C, 1, 1], no bias (model.py:173)
     v_in = _rfb(_drop(v, masks, "att_v"), fwd=True, bwd=False, on=bf16)                          # model.py:185
     vv = _rfb(torch.einsum("bchw,mc->bmhw", v_in, wv[:, :, 0, 0]), fwd=False, bwd=True, on=bf16)
-    qq = _drop(q, masks, "att_q") @ sd["attention.q_lin.weight"].t() + sd["attention.q_lin.bias"]  # model.py:186
+    qq = _linear16(_drop(q, masks, "att_q"), sd["attention.q_lin.weight"], sd["attention.q_lin.bias"],
+                   bf16 and fc16_dims_ok(sd))                                                     # model.py:186
     qq = qq[:, :, None, None].expand_as(vv)     # tile_question_over_image (model.py:224-231)
     # bf16 path: x = relu(v' (+|*) q') is stored as bf16 (the v' half only for '|': the q' half is never materialised)
     if do_option == "*":
@@ -218,10 +236,11 @@ def image_question_attention(v: Tensor, att: Tensor) -> Tuple[Tensor, Tensor]:
     return out, p
 
 
-def classifier(sd: Dict[str, Tensor], x: Tensor, masks: Optional[dict] = None) -> Tensor:
+def classifier(sd: Dict[str, Tensor], x: Tensor, masks: Optional[dict] = None, bf16: bool = False) -> Tensor:
     """Classifier: Dropout -> Linear -> ReLU -> Dropout -> Linear (model.py:198-205)."""
-    h = torch.relu(_drop(x, masks, "cls1") @ sd["classifier.lin1.weight"].t() + sd["classifier.lin1.bias"])
-    return _drop(h, masks, "cls2") @ sd["classifier.lin2.weight"].t() + sd["classifier.lin2.bias"]
+    on = bf16 and fc16_dims_ok(sd)
+    h = torch.relu(_linear16(_drop(x, masks, "cls1"), sd["classifier.lin1.weight"], sd["classifier.lin1.bias"], on))
+    return _linear16(_drop(h, masks, "cls2"), sd["classifier.lin2.weight"], sd["classifier.lin2.bias"], on)
 
 
 def vqa_forward(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: Tensor,
@@ -234,7 +253,7 @@ def vqa_forward(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: T
     qf = question_encoder(sd, q, q_len, cfg["text"]["bidirectional"], masks)
     att = attention_scores(sd, vn, qf, cfg["attention"]["do_option"], masks, bf16)
     wv, probs = image_question_attention(vn, att)              # the weighted sum sees v WITHOUT attention.drop
-    logits = classifier(sd, torch.cat([wv, qf], dim=1), masks)
+    logits = classifier(sd, torch.cat([wv, qf], dim=1), masks, bf16)
     if stages is not None:
         stages.update(image=img, vnorm=vn, question=qf, attention=att, probs=probs,
                       weighted=wv, logits=logits)

@@ -45,3 +45,20 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libvqa_hip.so")
     with pytest.raises(_lib.VqaHipError):
         _lib.load()
+
+
+def test_no_kernel_carries_a_large_private_segment():
+    """a workgroup-barrier kernel with 512 bytes of scratch per lane deadlocked the GPU beyond ~2 000 resident
+    waves (the round-2 hang, reproduced and bisected in round 3).  Read every gfx950 kernel's private segment size from the
+    code objects of the built library: none may exceed the 256 bytes per lane the launch-time guard (ensure_dyn_smem) allows."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_scratch import kernel_scratch
+    from dl_vqa_amd import _lib, build
+    build.build_library(verbose=False)
+    ks = kernel_scratch(_lib.LIB_PATH)
+    assert len(ks) > 200
+    worst = max(ks.items(), key=lambda kv: kv[1][0])
+    print(f"largest private segment: {worst[1][0]} bytes per lane ({worst[0][:80]})")
+    big = {k: v for k, v in ks.items() if v[0] > 256}
+    assert not big, big

@@ -87,6 +87,27 @@ def test_gemm_bf16_epilogue_and_bf16_output():
     assert torch.equal(Cb.cpu(), Cf.cpu().to(torch.bfloat16))        # the bf16 result is the rounded fp32 result
 
 
+@pytest.mark.parametrize("Bn,P,K,N", [(3, 200, 256, 256), (2, 676, 64, 1024), (5, 129, 96, 136)])
+def test_gemm_bf16_staged_bf16_output(Bn, P, K, N):
+    """bf16 result of 128 x 128 tiles: interior tiles store through the wave-private LDS scratch (16 bytes per lane), edge
+    tiles keep the element-wise stores; row-group term (one / two groups per tile), bias, ReLU.  The bf16 result must be
+    the rounded fp32 result of the same GEMM, element for element."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(Bn * 100 + N)
+    M = Bn * P
+    A, W = rb(torch.randn(M, K, generator=g)), rb(torch.randn(N, K, generator=g))
+    b1, rg = torch.randn(N, generator=g), torch.randn(Bn, N, generator=g)
+    ref = torch.relu(A.double() @ W.double().t() + rg.double().repeat_interleave(P, dim=0) + b1.double())
+    Cf = torch.empty(M, N, device=DEV)
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    for C in (Cf, Cb):
+        ops.gemm_bf16(A.to(torch.bfloat16).to(DEV), W.to(torch.bfloat16).to(DEV), C, M, N, K, bias1=b1.to(DEV),
+                      rowgroup=rg.to(DEV), rg_div=P, relu=True)
+    torch.cuda.synchronize()
+    check(f"gemm_bf16 staged epilogue fp32 out {M}x{N}x{K}", Cf, ref, 1e-5)
+    assert torch.equal(Cb.cpu(), Cf.cpu().to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co,stride", [(2, 30, 30, 64, 128, 1), (1, 30, 34, 128, 256, 1), (3, 22, 20, 64, 64, 1),
                                                 (2, 41, 37, 64, 128, 2), (2, 58, 58, 64, 128, 1)])
 def test_conv_bf16_fwd_dgrad_wgrad(B, H, W, Ci, Co, stride):

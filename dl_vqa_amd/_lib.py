@@ -68,7 +68,7 @@ PROTOTYPES = {
     "vqa_dropout": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_dropout_add": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp, i32, f32, u64, vp]),
-    "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, f32p, i64, i32, f32, u64, vp]),
+    "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, vp, i32, i64, i32, f32, u64, vp]),
     "vqa_embed_tanh_fwd": (i32, [i64p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp, vp]),
     "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
     "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
@@ -98,6 +98,8 @@ PROTOTYPES = {
     "vqa_gemm_bf16_workspace_bytes": (i64, [i32, i32, i32]),
     "vqa_gemm_bf16": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i32, i32, i32, i32, f32p, f32p,
                             f32p, i64, i32, i32, i32, i32, f32p, f32p, i64, i32, vp]),
+    "vqa_gemm_tall_bf16_supported": (i32, [i32, i32, i32, i32, i32]),
+    "vqa_gemm_tall_bf16": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, f32p, i64, i32, i32, i32, i32, vp]),
     "vqa_conv_pack_weights_bf16": (i32, [f32p, vp, vp, i32, i32, i32, vp]),
     "vqa_conv3x3_relu_pool_fwd_bf16": (i32, [vp, vp, f32p, vp, i32, u8p, i32, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_conv3x3_dgrad_bf16": (i32, [vp, u8p, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -703,12 +703,23 @@ __global__ __launch_bounds__(256) void pconv_bias_part_kernel(const uint16_t* dp
     part[(int64_t)blockIdx.x * Co + co] = s;
   }
 }
+// dbias[co] = sum of the parts, in a fixed order: a block takes 32 channels, its 8 part lanes stride over the parts and
+// are combined through LDS (the one-thread-per-channel form was a chain of 1 024 dependent loads: 255 us)
 __global__ __launch_bounds__(256) void pconv_bias_reduce_kernel(const float* part, float* dbias, int parts, int Co) {
-  const int co = blockIdx.x * blockDim.x + threadIdx.x;
-  if (co >= Co) return;
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int co = blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int p = 0; p < parts; ++p) s += part[(int64_t)p * Co + co];
-  dbias[co] = s;
+  if (co < Co)
+    for (int p = pl; p < parts; p += 8) s += part[(int64_t)p * Co + co];
+  red[pl][c] = s;
+  __syncthreads();
+  if (pl == 0 && co < Co) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) t += red[l][c];
+    dbias[co] = t;
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -908,7 +919,7 @@ int vqa_pconv_wgrad(const void* x, const void* dy_pad, int Hd, int Wd, const voi
                      static_cast<const uint16_t*>(dpooled), argmax, bpart, windows, Co, per);
   rc = check_hip(hipGetLastError(), "pconv_bias_part launch");
   if (rc) return rc;
-  hipLaunchKernelGGL(pconv_bias_reduce_kernel, dim3((Co + 255) / 256), dim3(256), 0, s, bpart, dbias, parts, Co);
+  hipLaunchKernelGGL(pconv_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bpart, dbias, parts, Co);
   return check_hip(hipGetLastError(), "pconv_bias_reduce launch");
 }
 

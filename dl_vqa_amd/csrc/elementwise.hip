@@ -109,8 +109,12 @@ __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, i
   }
 }
 
-__global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float* norm, float* dpooled,
+// OB: the gradient is stored as bf16 (bf16 path: it is the pooled gradient of the last conv block, staged as bf16 anyway)
+template <bool OB>
+__global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float* norm, void* dpooled_,
                                   int64_t rows, int C, float p, float inv_keep, uint64_t seed) {
+  float* const dpooled = static_cast<float*>(dpooled_);
+  uint16_t* const dpooled16 = static_cast<uint16_t*>(dpooled_);
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -128,6 +132,7 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
     const float inv = 1.0f / (n + 1e-12f);
     const float k = n > 0.f ? dot * (n + 1e-12f) / n : 0.f;
     float4* dst = reinterpret_cast<float4*>(dpooled + r * C);
+    uint2* dst16 = reinterpret_cast<uint2*>(dpooled16 + r * C);
     for (int c = lane; c < nch; c += 64) {
       const float4 a = g[c], b = v[c];
       float4 d = make_float4((a.x - b.x * k) * inv, (a.y - b.y * k) * inv, (a.z - b.z * k) * inv, (a.w - b.w * k) * inv);
@@ -135,7 +140,13 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
         const uint64_t e = (uint64_t)r * C + 4 * c;
         { const float4 ds_ = drop_scale4(seed, e, p, inv_keep); d.x *= ds_.x; d.y *= ds_.y; d.z *= ds_.z; d.w *= ds_.w; }
       }
-      dst[c] = d;
+      if (OB) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const bf2 lo = {(__bf16)d.x, (__bf16)d.y}, hi = {(__bf16)d.z, (__bf16)d.w};
+        dst16[c] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+      } else {
+        dst[c] = d;
+      }
     }
   }
 }
@@ -812,13 +823,17 @@ int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, in
   return check_hip(hipGetLastError(), "l2norm_fwd launch");
 }
 
-int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, float* dpooled, int64_t rows, int C,
-                   float p, uint64_t seed, vqa_stream_t stream) {
+int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, void* dpooled, int dpooled_is_bf16, int64_t rows,
+                   int C, float p, uint64_t seed, vqa_stream_t stream) {
   set_launch_tag(-1);
   ProfScope prof(VQA_K_L2NORM_BWD, (hipStream_t)stream);
   VQA_REQUIRE(dvn && vn && norm && dpooled && rows > 0 && C % 4 == 0, "vqa_l2norm_bwd: bad args");
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
-                     C, p, KEEP(p), seed);
+  if (dpooled_is_bf16)
+    hipLaunchKernelGGL(l2norm_bwd_kernel<true>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
+                       C, p, KEEP(p), seed);
+  else
+    hipLaunchKernelGGL(l2norm_bwd_kernel<false>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
+                       C, p, KEEP(p), seed);
   return check_hip(hipGetLastError(), "l2norm_bwd launch");
 }
 

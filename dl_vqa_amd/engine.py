@@ -352,7 +352,12 @@ class Engine:
         xs = torch.empty(B * Pn, mid, dtype=torch.bfloat16 if self.bf16 else torch.float32, device=dev)
         mode = self.att_mode
         vprime = new(B * Pn, mid) if (mode == 1 and keep) else None
-        if self.bf16:
+        if self.bf16 and vprime is None and os.environ.get("VQA_TALL_GEMM", "1") != "0" and \
+                ops.gemm_tall_bf16_supported(B * Pn, mid, C, Pn, mode != 2):
+            # tall GEMM with K = C only: persistent 256 x 128 tiles (csrc/gemm_tall_bf16.hip)
+            ops.gemm_tall_bf16(v16.view(B * Pn, C), wv16, xs, B * Pn, mid, C, rowgroup=(qp if mode != 2 else None),
+                               rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, tag=21)
+        elif self.bf16:
             ops.gemm_bf16(v16.view(B * Pn, C), wv16, xs, B * Pn, mid, C, rowgroup=(qp if mode != 2 else None),
                           rg_div=Pn, rg_op=(1 if mode == 1 else 0), relu=True, aux=vprime, tag=21)
         else:
@@ -575,9 +580,8 @@ class Engine:
             main.wait_event(ev0)
 
         # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first
-        dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE)).view_as(ctx.acts[-1])
-        if self.bf16:
-            dP = ops.to_bf16(dP)
+        dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE),
+                            out_dtype=torch.bfloat16 if self.bf16 else torch.float32).view_as(ctx.acts[-1])
         for l in range(self.L - 1, -1, -1):
             if l == 0 and ctx.fast0:
                 if self.bf16:

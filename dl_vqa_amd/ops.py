@@ -238,10 +238,12 @@ def l2norm_fwd(pooled: torch.Tensor, p: float, seed: int, drop2=None):
     return vn, norm, vd
 
 
-def l2norm_bwd(dvn, vn, norm, p: float, seed: int, out=None):
+def l2norm_bwd(dvn, vn, norm, p: float, seed: int, out=None, out_dtype=torch.float32):
+    """out_dtype=torch.bfloat16: the gradient is stored as bf16 (the bf16 path's pooled gradient of the last conv block)."""
     C = vn.shape[-1]
-    d = out if out is not None else torch.empty_like(vn)
-    call("vqa_l2norm_bwd", ptr(dvn), ptr(vn), ptr(norm), ptr(d), vn.numel() // C, C, p, seed, stream())
+    d = out if out is not None else torch.empty(vn.shape, dtype=out_dtype, device=vn.device)
+    call("vqa_l2norm_bwd", ptr(dvn), ptr(vn), ptr(norm), ptr(d), int(d.dtype == torch.bfloat16), vn.numel() // C, C, p, seed,
+         stream())
     return d
 
 
@@ -453,6 +455,19 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int,
          M, N, K, ptr(bias1), ptr(bias2), ptr(rowgroup), (rowgroup.stride(0) if rowgroup is not None else 0),
          rg_div, rg_op, int(relu), int(accumulate), ptr(aux), ptr(ws), (ws.numel() * 4 if ws is not None else 0),
          tag, stream())
+    return C
+
+
+def gemm_tall_bf16_supported(M: int, N: int, K: int, rg_div: int = 0, has_rowgroup: bool = False) -> bool:
+    return bool(_lib.load().vqa_gemm_tall_bf16_supported(M, N, K, rg_div, int(has_rowgroup)))
+
+
+def gemm_tall_bf16(A: torch.Tensor, W: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, *, rowgroup=None, rg_div=1,
+                   rg_op=0, relu=False, tag=0) -> torch.Tensor:
+    """C [M,N] bf16 = act(A [M,K] . W [N,K]^T (+|*) rowgroup[row // rg_div]) on persistent 256 x 128 tiles (short K)."""
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and C.dtype == torch.bfloat16
+    call("vqa_gemm_tall_bf16", ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(C), C.stride(0), M, N, K, ptr(rowgroup),
+         (rowgroup.stride(0) if rowgroup is not None else 0), rg_div, rg_op, int(relu), tag, stream())
     return C
 
 

@@ -150,8 +150,9 @@ int vqa_dropout_add(const float* x, float* y, int64_t n, float p, uint64_t seed,
  * (models/model.py:185), i.e. the v_conv operand, written in the same pass. */
 int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p,
                    uint64_t seed, void* vdrop, int vdrop_is_bf16, float p2, uint64_t seed2, vqa_stream_t stream);
-int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, float* dpooled, int64_t rows,
-                   int C, float p, uint64_t seed, vqa_stream_t stream);
+int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, void* dpooled,
+                   int dpooled_is_bf16 /* bf16 path: the gradient is stored as bf16 (no separate conversion pass) */,
+                   int64_t rows, int C, float p, uint64_t seed, vqa_stream_t stream);
 
 /* ---- question encoder (models/model.py:134-166 questionNet) ----------------------------------
  * x[t][b][:] = tanh(dropout(emb[q[b][t]]))   (embedding -> drop -> tanh, model.py:155-157).
@@ -287,6 +288,14 @@ int vqa_gemm_bf16(const void* A, int64_t lda, int transA, const void* B, int64_t
                   int64_t ldc, int c_is_bf16, int M, int N, int K, const float* bias1, const float* bias2,
                   const float* rowgroup, int64_t rg_ld, int rg_div, int rg_op, int relu, int accumulate,
                   float* aux, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
+
+/* Tall bf16 GEMM with a short reduction (csrc/gemm_tall_bf16.hip): C[M][N] = act(A[M][K] . W[N][K]^T (+|*) rowgroup), bf16
+ * result -- the v_conv forward of the bf16 path (models/model.py:173,187-193: M = B * positions, N = mid, K = image
+ * features).  Persistent 256 x 128 tiles, LDS-DMA staging across tile boundaries, 16-byte stores.  Operands as
+ * vqa_gemm_bf16 with transA = 0, transB = 1; rowgroup (optional) [M / rg_div][N] fp32, rg_op 0 = add, 1 = multiply. */
+int vqa_gemm_tall_bf16_supported(int M, int N, int K, int rg_div, int has_rowgroup);
+int vqa_gemm_tall_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                       const float* rowgroup, int64_t rg_ld, int rg_div, int rg_op, int relu, int tag, vqa_stream_t stream);
 
 /* Convolution blocks of the bf16 path (models/model.py:80-82 and their autograd): activations NHWC bf16, weights
  * re-packed per step to bf16 as wfT [Co][9*CiP] and wdT [CiP][9*Co] (K index = (tap, channel)), arg-max bytes and

@@ -87,6 +87,29 @@ def test_gemm_bf16_epilogue_and_bf16_output():
     assert torch.equal(Cb.cpu(), Cf.cpu().to(torch.bfloat16))        # the bf16 result is the rounded fp32 result
 
 
+@pytest.mark.parametrize("Bn,P,K,N,op", [(8, 676, 256, 1024, 0), (3, 2916, 256, 256, 1), (40, 300, 64, 512, 0), (17, 1000, 192, 128, None)])
+def test_gemm_tall_bf16(Bn, P, K, N, op):
+    """csrc/gemm_tall_bf16.hip (persistent 256 x 128 tiles, short K) against the float64 product of the bf16-rounded
+    operands: row-group add / multiply / none, ReLU, tiles that span two groups, a last row tile that is partly past M,
+    several tiles per workgroup.  The result must equal the rounded fp32 result of vqa_gemm_bf16 up to summation order."""
+    ops = _ops()
+    M = Bn * P
+    assert ops.gemm_tall_bf16_supported(M, N, K, P, op is not None)
+    g = torch.Generator().manual_seed(Bn * 7 + K)
+    A, W = rb(torch.randn(M, K, generator=g)), rb(torch.randn(N, K, generator=g))
+    rg = torch.randn(Bn, N, generator=g)
+    acc = A.double() @ W.double().t()
+    rgx = rg.double().repeat_interleave(P, dim=0)
+    ref = torch.relu(acc if op is None else (acc * rgx if op == 1 else acc + rgx))
+    C = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_tall_bf16(A.to(torch.bfloat16).to(DEV), W.to(torch.bfloat16).to(DEV), C, M, N, K,
+                       rowgroup=(rg.to(DEV) if op is not None else None), rg_div=P, rg_op=(op or 0), relu=True)
+    torch.cuda.synchronize()
+    check(f"gemm_tall_bf16 {M}x{N}x{K} op={op}", C.float(), ref, 2 ** -7)
+    near = ref.float().to(torch.bfloat16)
+    assert float((C.cpu() != near).float().mean()) < 2e-3          # a bf16 rounding flips only where fp32 sums differ in the last bit
+
+
 @pytest.mark.parametrize("Bn,P,K,N", [(3, 200, 256, 256), (2, 676, 64, 1024), (5, 129, 96, 136)])
 def test_gemm_bf16_staged_bf16_output(Bn, P, K, N):
     """bf16 result of 128 x 128 tiles: interior tiles store through the wave-private LDS scratch (16 bytes per lane), edge

@@ -31,38 +31,40 @@ for (Hin, Ci, Co) in ((h1, 64, 128), (h2, 128, 256)):
 
 
 def fwd(L, l):
-    if bf:
-        return ops.conv_fwd_bf16(L["x"], L["wf"], L["b"], 1, out_dtype=torch.float32 if L["last"] else torch.bfloat16, tag=l + 1)
+    if bf:      # the engine's bf16 path: patch kernels on channel-blocked (C16) activations
+        return ops.pconv_fwd(L["xc"], L["wf"], L["b"], L["w"].shape[0], out_dtype=torch.float32 if L["last"] else torch.bfloat16, tag=l + 1)
     return ops.conv_fwd(L["x"], L["wf"], L["b"], 1, tag=l + 1)
 
 
 def wgrad(L, l):
     if bf:
-        return ops.conv_wgrad_bf16(L["x"], L["dp"], L["am"], L["dw"], L["db"], 1, tag=l + 1)
+        return ops.pconv_wgrad(L["xc"], L["dyp"], L["dp"], L["am"], L["dw"], L["db"], tag=l + 1)
     return ops.conv_wgrad(L["x"], L["dp"], L["am"], L["dw"], L["db"], 1, tag=l + 1)
 
 
 def dgrad(L, l):
     if bf:
-        return ops.conv_dgrad_bf16(L["dp"], L["am"], L["wd"], L["x"].shape, 1, tag=l + 1)
+        L["dyp"] = ops.pconv_expand_dy(L["dp"], L["am"], L["x"].shape[1], L["x"].shape[2])
+        return ops.pconv_dgrad(L["dyp"], L["wd"], L["x"].shape, tag=l + 1)
     return ops.conv_dgrad(L["dp"], L["am"], L["wd"], L["x"].shape, 1, tag=l + 1, out=L["dx"])
 
 
 for l, L in enumerate(layers):          # set-up launches, same layer order as the measured ones
     if bf:
-        L["wf"], L["wd"] = ops.conv_pack_weights_bf16(L["w"], L["x"].shape[3], need_wd=True)
+        L["wf"], L["wd"] = ops.pconv_pack_weights(L["w"])
+        L["xc"] = ops.to_c16(L["x"])
     else:
         L["wf"], L["wd"] = ops.conv_pack_weights(L["w"], L["x"].shape[3])
     L["pooled"], L["am"] = fwd(L, l)
-    L["dp"] = torch.randn(L["pooled"].shape, device=dev).to(torch.bfloat16 if bf else torch.float32)
+    L["dp"] = torch.randn(L["am"].shape, device=dev).to(torch.bfloat16 if bf else torch.float32)
     L["dw"], L["db"] = torch.empty_like(L["w"]), torch.empty_like(L["b"])
     L["dx"] = None if bf else torch.empty_like(L["x"])
-    wgrad(L, l)
     dgrad(L, l)
+    wgrad(L, l)
 for _ in range(3):
     for l, L in enumerate(layers):
         fwd(L, l)
-        wgrad(L, l)
         dgrad(L, l)
+        wgrad(L, l)
 torch.cuda.synchronize()
 print(f"pmc_conv_run: dtype={args.dtype} batch={B} size={args.size} done")

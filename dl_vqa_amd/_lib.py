@@ -68,7 +68,7 @@ PROTOTYPES = {
     "vqa_dropout": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_dropout_add": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp, i32, f32, u64, vp]),
-    "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, vp, i32, i64, i32, f32, u64, vp]),
+    "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, vp, i32, i64, i32, i32, f32, u64, vp]),
     "vqa_embed_tanh_fwd": (i32, [i64p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp, vp]),
     "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
     "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
@@ -109,12 +109,10 @@ PROTOTYPES = {
     "vqa_pconv_weights_bytes": (i64, [i32, i32]),
     "vqa_pconv_pack_weights": (i32, [f32p, vp, vp, i32, i32, vp]),
     "vqa_pconv_fwd": (i32, [vp, vp, f32p, vp, i32, u8p, i32, i32, i32, i32, i32, i32, vp]),
-    "vqa_pconv_expand_dy": (i32, [vp, u8p, vp, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_pconv_wgrad_supported": (i32, [i32, i32, i32, i32]),
     "vqa_pconv_wgrad_workspace_bytes": (i64, [i32, i32, i32, i32, i32]),
-    "vqa_pconv_wgrad": (i32, [vp, vp, i32, i32, vp, u8p, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, i32, vp]),
-    "vqa_pconv_dy_dims": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
-    "vqa_pconv_dgrad": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "vqa_pconv_wgrad": (i32, [vp, u8p, vp, f32p, f32p, i32, i32, i32, i32, i32, f32p, i64, i32, vp]),
+    "vqa_pconv_dgrad": (i32, [vp, u8p, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_adam": (i32, [f32p, f32p, f32p, f32p, i64, f32, f32, f32, f32, i32, f32, vp]),
 }
 

@@ -65,7 +65,7 @@ struct PcCfg {
   static constexpr int SCR = 4608;                   // wave-private epilogue scratch (>= 4 KiB: 32 pixels x 64 channels bf16)
   static constexpr int LDS_ALL = LDS + 8 * SCR;
   // global stores a wave issues per tile epilogue (the counted vmcnt wait of the stage that follows)
-  template <int EPI> static constexpr int nstores() { return EPI == 0 ? 8 : EPI == 1 ? 12 : 16; }
+  template <int EPI> static constexpr int nstores() { return EPI == 0 ? 8 : EPI == 1 ? 12 : 16; }   // EPI 3 does not count
 };
 
 struct PcParams {
@@ -74,7 +74,9 @@ struct PcParams {
   const char* wimg;     // packed weights [nslabs][Cin/16][9][NT][64 lanes][8] bf16
   const float* bias;    // [N] (forward) or null
   void* out;            // EPI 0: pooled bf16 C16 [B][N/16][Hp][Wp][16]; EPI 1: pooled fp32 [B][Hp][Wp][N]; plain: [B][Hc][Wc][N]
-  uint8_t* amax;        // forward: [B][Hp][Wp][N]
+  uint8_t* amax;        // forward: arg-max bytes, C16 [B][N/16][Hp][Wp][16]
+  const char* am_in;    // routed (backward-data) source: arg-max bytes of the block, C16 [B][Cin/16][Hq][Wq][16]; x = dP, C16 bf16
+  int Hq, Wq;           // routed source: pooled map size
   int B, H, W, Cin, N;  // input dims, output channels
   int Hc, Wc;           // computed output extent (forward: 2*Hp x 2*Wp; plain: H-2 x W-2)
   int Hp, Wp;           // forward only
@@ -127,14 +129,31 @@ struct PcTile {
   }
 };
 
-// EPI 0: bias + ReLU + 2x2 max-pool + arg-max, pooled stored as bf16; 1: the same, pooled fp32; 2: plain bf16 store;
-// 3: plain fp32 store (tests)
+// the 8 bf16 of d whose arg-max byte (id) equals j; zeros elsewhere
+__device__ __forceinline__ float4 pc_route8(float4 d, uint2 id, uint32_t j) {
+  const uint32_t jj = j * 0x01010101u;
+  auto bytemask = [&](uint32_t w) {
+    const uint32_t q = w ^ jj;                                   // 0 where the byte equals j (bytes are 0..4, j 0..3)
+    return (((0x80808080u - q) & 0x80808080u) >> 7) * 0xffu;
+  };
+  const uint32_t m0 = bytemask(id.x), m1 = bytemask(id.y);
+  float4 v;
+  v.x = __uint_as_float(__float_as_uint(d.x) & __builtin_amdgcn_perm(0u, m0, 0x01010000u));
+  v.y = __uint_as_float(__float_as_uint(d.y) & __builtin_amdgcn_perm(0u, m0, 0x03030202u));
+  v.z = __uint_as_float(__float_as_uint(d.z) & __builtin_amdgcn_perm(0u, m1, 0x01010000u));
+  v.w = __uint_as_float(__float_as_uint(d.w) & __builtin_amdgcn_perm(0u, m1, 0x03030202u));
+  return v;
+}
+
+// EPI 0: bias + ReLU + 2x2 max-pool + arg-max, pooled stored as bf16 C16; 1: the same, pooled fp32 NHWC; 2: plain bf16 NHWC
+// store; 3: plain fp32 NHWC store (tests); 4: plain bf16 C16 store
 // Epilogues 0-2 go through a wave-private LDS scratch (behind the two stages) so that HBM sees 16-byte-per-lane stores of
 // whole channel runs: the direct form (one 2-byte store per accumulator register) was store-ISSUE bound -- 64-128 store
 // instructions per wave and tile cost 7-11 us of a 20-60 us tile (measured with the stores skipped).
-template <int WMv, int EPI>
+template <int WMv, int EPI, bool RT>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
   using C = PcCfg<WMv>;
+  constexpr int NPW = RT ? C::WK : C::NP;            // DMA pieces a wave issues per stage (routed: the weights only)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -168,14 +187,16 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
 
   // ---- DMA source offsets of this wave's patch pieces i = wave + 8k (bytes from the tile's first pixel of the slice)
   uint32_t pvoff[C::PK];
+  if (!RT) {
 #pragma unroll
-  for (int k = 0; k < C::PK; ++k) {
-    const int i = wave + 8 * k;
-    const int o = i * 1024 + lane * 16;
-    const int p = o >> 5, slot = (o >> 4) & 1;
-    const int row = p / PC_RS, xx = p - row * PC_RS;
-    const int chunk = slot ^ ((p >> 3) & 1);
-    pvoff[k] = (i < C::PATCH_INSTR && row < C::PROWS) ? (uint32_t)((row * P.W + xx) * 32 + chunk * 16) : BUF_OOB;
+    for (int k = 0; k < C::PK; ++k) {
+      const int i = wave + 8 * k;
+      const int o = i * 1024 + lane * 16;
+      const int p = o >> 5, slot = (o >> 4) & 1;
+      const int row = p / PC_RS, xx = p - row * PC_RS;
+      const int chunk = slot ^ ((p >> 3) & 1);
+      pvoff[k] = (i < C::PATCH_INSTR && row < C::PROWS) ? (uint32_t)((row * P.W + xx) * 32 + chunk * 16) : BUF_OOB;
+    }
   }
   const pc_rsrc_t wrs = pc_rsrc(P.wimg);
   const uint32_t wlane = (uint32_t)lane * 16u;
@@ -195,23 +216,83 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
   int ns_buf = 0;
   bool ns_on = false;
   auto next_stage = [&](const PcTile& tp, int slice, int buf, bool on) {
-    const char* base = P.x + ((((int64_t)tp.img * P.nslices + slice) * P.H + tp.ty * C::TY) * P.W + tp.tx * PC_TX) * 32;
-    const int64_t left = P.x_end - base;
-    ns_rs = pc_rsrc(base, left > 0xffff0000LL ? 0xffff0000u : (uint32_t)left);
+    if (!RT) {
+      const char* base = P.x + ((((int64_t)tp.img * P.nslices + slice) * P.H + tp.ty * C::TY) * P.W + tp.tx * PC_TX) * 32;
+      const int64_t left = P.x_end - base;
+      ns_rs = pc_rsrc(base, left > 0xffff0000LL ? 0xffff0000u : (uint32_t)left);
+    }
     ns_wsrc = (uint32_t)((slab * P.nslices + slice) * C::W_BYTES);
     ns_buf = buf;
     ns_on = on;
   };
   auto issue_piece = [&](int n) {        // n is a compile-time constant at every call
     if (!ns_on) return;
-    if (n < C::PK) {
+    if (!RT && n < C::PK) {
       const int i = wave + 8 * n;
       if (i < C::PATCH_INSTR)
         lds_dma16(ns_rs, smem + ns_buf * C::PATCH_BYTES + i * 1024, pvoff[n < C::PK ? n : 0], 0u);
     } else if (n < C::NP) {
-      const int i = wave + 8 * (n - C::PK);
-      if (i < C::W_INSTR)
+      const int i = wave + 8 * (RT ? n : n - C::PK);
+      if (i < C::W_INSTR && (!RT || n < C::WK))
         lds_dma16(wrs, smem + 2 * C::PATCH_BYTES + ns_buf * C::W_BYTES + i * 1024, wlane, ns_wsrc + i * 1024);
+    }
+  };
+
+  // ---- routed patches (backward-data): the patch of a slice is BUILT in LDS from the block's pooled gradient and arg-max
+  // bytes -- pre-pool gradient dY(y, x) = dP(y/2, x/2) where the stored byte equals the pixel's place in its window, zero
+  // elsewhere (border of two pixels, rows / columns the pool dropped, dead windows) -- instead of being copied from a
+  // materialised map four times the size.  A task = (pooled pixel of the (PROWS/2) x 17 under the patch, 8-channel half):
+  // 16 bytes of dP + 8 arg-max bytes -> four 16-byte chunks (pc_route8), one per pixel of the window.  Thread t takes tasks
+  // t, t + 512; the loads for stage q + 2 are issued during stage q (behind tap 1), routed into the other buffer during
+  // stage q + 1 (behind tap 0), read by the MFMAs of stage q + 2.
+  constexpr int RT_PR = C::PROWS / 2, RT_TASKS = RT_PR * 17 * 2, RT_K = (RT_TASKS + 511) / 512;
+  bool rt_ok[RT_K];
+  int rt_prow[RT_K], rt_pcol[RT_K];
+  uint32_t rt_a0[RT_K], rt_a1[RT_K];
+  const int rt_hb = threadIdx.x & 1;
+  float4 rt_d[RT_K];
+  uint2 rt_a[RT_K];
+  PcTile rt_tile = cur;
+  int rt_slice = 0, rt_count = 0;
+  const int rt_total = my_tiles * P.nslices;
+  if (RT) {
+#pragma unroll
+    for (int k = 0; k < RT_K; ++k) {
+      const int tid = k * 512 + (int)threadIdx.x, pp = tid >> 1;
+      rt_ok[k] = tid < RT_TASKS;
+      rt_prow[k] = pp / 17;
+      rt_pcol[k] = pp - rt_prow[k] * 17;
+      const int p = 2 * rt_prow[k] * PC_RS + 2 * rt_pcol[k], sw = (p >> 3) & 1;     // p is even: p, p + 1 share the swizzle bit;
+      rt_a0[k] = (uint32_t)(p * 32 + 16 * (rt_hb ^ sw));                            // the row below (p + 40) has the other one
+      rt_a1[k] = (uint32_t)((p + PC_RS) * 32 + 16 * (rt_hb ^ sw ^ 1));
+    }
+  }
+  auto rt_load = [&]() {           // ALWAYS issues its 2 RT_K loads (the counted waits rely on it); past the stream: zeros
+    const bool on = rt_count < rt_total;
+    const int64_t plane = ((int64_t)rt_tile.img * P.nslices + rt_slice) * P.Hq * P.Wq;
+    const uint32_t pbytes = (uint32_t)(P.Hq * P.Wq * 32);
+    const __amdgpu_buffer_rsrc_t rd = buf_rsrc(P.x + plane * 32, pbytes), ra = buf_rsrc(P.am_in + plane * 16, pbytes >> 1);
+    const int py0 = rt_tile.ty * (C::TY / 2) - 1, px0 = rt_tile.tx * (PC_TX / 2) - 1;
+#pragma unroll
+    for (int k = 0; k < RT_K; ++k) {
+      const int py = py0 + rt_prow[k], px = px0 + rt_pcol[k];
+      const bool ok = on && rt_ok[k] && (unsigned)py < (unsigned)P.Hq && (unsigned)px < (unsigned)P.Wq;
+      const uint32_t o = (uint32_t)((py * P.Wq + px) * 2 + rt_hb);
+      rt_d[k] = buf_load16(rd, ok ? o * 16u : BUF_OOB);
+      rt_a[k] = buf_load8(ra, ok ? o * 8u : BUF_OOB);
+    }
+    ++rt_count;
+    if (++rt_slice == P.nslices) { rt_slice = 0; rt_tile.advance(dlt, P.tiles_y, P.tiles_x); }
+  };
+  auto rt_route = [&](int buf) {   // the registers -> the four pixels of each task's window, in patch buffer `buf`
+    char* const dst = smem + buf * C::PATCH_BYTES;
+#pragma unroll
+    for (int k = 0; k < RT_K; ++k) {
+      if (rt_ok[k]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(dst + ((j >> 1) ? rt_a1[k] : rt_a0[k]) + (j & 1) * 32) = pc_route8(rt_d[k], rt_a[k], (uint32_t)j);
+      }
     }
   };
 
@@ -227,7 +308,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
 
   next_stage(nxt, 0, 0, true);
 #pragma unroll
-  for (int n = 0; n < C::NP; ++n) issue_piece(n);
+  for (int n = 0; n < NPW; ++n) issue_piece(n);
+  if (RT) {
+    rt_load();
+    rt_route(0);
+    rt_load();
+  }
   int buf = 0;
   bool after_epilogue = false;
   for (int k = 0; k < my_tiles; ++k) {
@@ -274,7 +360,13 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
           for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b[t & 1][j]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t == 0) {
+        if (RT) {
+          // routed: the patch of the next stage behind tap 0 (its registers were loaded a stage ago), the loads for the stage
+          // after that behind tap 1, the weight pieces behind taps 2 ..
+          if (t == 0) { if (ns_on) rt_route(buf ^ 1); }
+          else if (t == 1) rt_load();
+          else if (t < 8) issue_piece(t - 2);
+        } else if (t == 0) {
           issue_piece(0);
           if (C::NP == 9) issue_piece(1);
         } else if (t < 8) {
@@ -316,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
               const int wx = 8 * ii + 2 * g + h;
               if (EPI == 0) *reinterpret_cast<uint16_t*>(scr + (((r >> 4) * 16 + wx) * 16 + (r & 15)) * 2) = bf16_bits(best > 0.f ? best : 0.f);
               else *reinterpret_cast<float*>(scr + (wx * 32 + r) * 4) = best > 0.f ? best : 0.f;
-              *reinterpret_cast<uint8_t*>(scr + AO + wx * 32 + r) = best > 0.f ? (uint8_t)am : (uint8_t)4;
+              *reinterpret_cast<uint8_t*>(scr + AO + ((r >> 4) * 16 + wx) * 16 + (r & 15)) = best > 0.f ? (uint8_t)am : (uint8_t)4;
             }
           }
           asm volatile("" ::: "memory");       // scratch: the wave's LDS accesses execute in order; keep the compiler's order too
@@ -345,12 +437,13 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
                                                        ok ? (int)(wx * P.N * 4 + inrun) : (int)BUF_OOB, 0, 0);
               }
             }
-            const __amdgpu_buffer_rsrc_t ra = buf_rsrc(P.amax + o_nhwc);
-            {
-              const int wx = lane >> 1, inrun = (lane & 1) * 16;    // 512 arg-max bytes: the lower 32 lanes
+            {   // 512 arg-max bytes, C16 like the activations: the lower 32 lanes, lane = (block, window)
+              const int64_t a16 = (((int64_t)img * (P.N / 16) + colt / 16) * plane + (int64_t)py * P.Wp + px0) * 16;
+              const __amdgpu_buffer_rsrc_t ra = buf_rsrc(P.amax + a16);
+              const int blk = (lane >> 4) & 1, wx = lane & 15;
               const float4 v = *reinterpret_cast<const float4*>(scr + AO + (lane & 31) * 16);
               const bool ok = rowok && lane < 32 && px0 + wx < P.Wp;
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ra, ok ? (int)(wx * P.N + inrun) : (int)BUF_OOB, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ra, ok ? (int)(blk * (int)plane * 16 + wx * 16) : (int)BUF_OOB, 0, 0);
             }
           }
           asm volatile("" ::: "memory");
@@ -380,6 +473,35 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
           const bool ok = ya + dy < P.Hc && xa + col < P.Wc;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
                                                  ok ? (int)((dy * P.Wc + col) * P.N * 2 + inrun) : (int)BUF_OOB, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+      }
+    } else if (EPI == 4) {
+      // the same rounds, C16 output [B][N/16][Hc][Wc][16] (the pooled gradient of the block below, read by its routed patches):
+      // scratch [16-channel block][row][pixel][16], a 1-KiB store instruction = one block's 2 x 16 pixels
+      const int64_t cplane = (int64_t)P.Hc * P.Wc;
+      char* const scr4 = scr + ((r >> 4) * 32 + 2 * h) * 32 + (r & 15) * 2;
+      const int st_dy = lane >> 5, st_col = (lane >> 1) & 15;
+      const int st_off = (st_dy * P.Wc + st_col) * 32 + (lane & 1) * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int pp = ((e >> 1) & 1) * 16 + 4 * (e >> 2) + (e & 1);          // + 2 h: in scr4
+            *reinterpret_cast<uint16_t*>(scr4 + (2 * j * 32 + pp) * 32) = bf16_bits(acc[i][j][e]);
+          }
+        asm volatile("" ::: "memory");
+        const int ya = y0 + wm * 4 + 2 * (i >> 1), xa = x0 + 16 * (i & 1);
+        const int64_t o0 = ((((int64_t)img * (P.N / 16) + (n_slab0 + wn * 64) / 16) * P.Hc + ya) * P.Wc + xa) * 16;
+        const __amdgpu_buffer_rsrc_t ro = buf_rsrc(static_cast<uint16_t*>(P.out) + o0);
+        const bool ok = ya + st_dy < P.Hc && xa + st_col < P.Wc;
+        const int vo = ok ? st_off : (int)BUF_OOB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(scr + q * 1024 + lane * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, q * (int)cplane * 32, 0);
         }
         asm volatile("" ::: "memory");
       }
@@ -447,75 +569,6 @@ __global__ void pconv_pack_kernel(const float* w, uint16_t* img, int Co, int Ci,
   *reinterpret_cast<uint4*>(img + idx * 8) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
-// ------------------------------------------------------------------ pre-pool gradient, materialised
-// dy_pad (bf16, C16: [B][C/16][Hd][Wd][16]): dY(y = yy-2, x = xx-2) = dP(window) where the stored arg-max byte equals the
-// pixel's position in its window, zero elsewhere (border of 2, pixels the pool does not cover, dead windows, and the padding
-// up to Hd x Wd that lets the weight-gradient tiles overhang the map without masks).  dP / arg-max are NHWC.
-// A workgroup takes (image, row yy, run of 32 pixels): the 17 windows under the run are read as whole NHWC rows into LDS
-// (coalesced), every thread then routes 8 channels of one pixel and the 64 lanes of a wave write one 1-KiB run of one
-// 16-channel block (coalesced).
-__device__ __forceinline__ float4 pc_route8(float4 d, uint2 id, uint32_t j) {
-  const uint32_t jj = j * 0x01010101u;
-  auto bytemask = [&](uint32_t w) {
-    const uint32_t q = w ^ jj;                                   // 0 where the byte equals j (bytes are 0..4, j 0..3)
-    return (((0x80808080u - q) & 0x80808080u) >> 7) * 0xffu;
-  };
-  const uint32_t m0 = bytemask(id.x), m1 = bytemask(id.y);
-  float4 v;
-  v.x = __uint_as_float(__float_as_uint(d.x) & __builtin_amdgcn_perm(0u, m0, 0x01010000u));
-  v.y = __uint_as_float(__float_as_uint(d.y) & __builtin_amdgcn_perm(0u, m0, 0x03030202u));
-  v.z = __uint_as_float(__float_as_uint(d.z) & __builtin_amdgcn_perm(0u, m1, 0x01010000u));
-  v.w = __uint_as_float(__float_as_uint(d.w) & __builtin_amdgcn_perm(0u, m1, 0x03030202u));
-  return v;
-}
-
-__global__ __launch_bounds__(256) void pconv_expand_dy_kernel(const uint16_t* dp, const uint8_t* am, uint16_t* dy,
-                                                             int B, int Hp, int Wp, int Hd, int Wd, int C) {
-  extern __shared__ __attribute__((aligned(16))) char elds[];       // [17 windows][C] bf16, then [17][C] bytes
-  char* const ldp = elds;
-  char* const lam = elds + 17 * C * 2;
-  const int runs = (Wd + 31) / 32, c8n = C / 8, nblk = C / 16;
-  const int64_t items = (int64_t)B * Hd * runs;
-  for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
-    const int run = (int)(it % runs);
-    const int yy = (int)((it / runs) % Hd);
-    const int b = (int)(it / ((int64_t)runs * Hd));
-    const int y = yy - 2, xx0 = 32 * run;
-    const bool rowok = y >= 0 && y < 2 * Hp;                        // uniform
-    const int w_lo = (xx0 - 2) >> 1;                                // may be -1
-    __syncthreads();                                                // the previous item's readers are done
-    if (rowok) {
-      for (int e = threadIdx.x; e < 17 * c8n; e += 256) {
-        const int wv = e / c8n, c8 = e - wv * c8n;
-        const int gw = w_lo + wv;
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint2 id = make_uint2(0x04040404u, 0x04040404u);            // outside the map: a dead window
-        if (gw >= 0 && gw < Wp) {
-          const int64_t wi = (((int64_t)b * Hp + (y >> 1)) * Wp + gw) * C + 8 * c8;
-          d = *reinterpret_cast<const float4*>(dp + wi);
-          id = *reinterpret_cast<const uint2*>(am + wi);
-        }
-        *reinterpret_cast<float4*>(ldp + (wv * C + 8 * c8) * 2) = d;
-        *reinterpret_cast<uint2*>(lam + wv * C + 8 * c8) = id;
-      }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nblk * 64; t += 256) {
-      const int blk = t >> 6, l = t & 63, xx = xx0 + (l >> 1), hf = l & 1;
-      if (xx >= Wd) continue;
-      const int x = xx - 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rowok && x >= 0 && x < 2 * Wp) {
-        const int wv = (x >> 1) - w_lo, ch = 16 * blk + 8 * hf;
-        const float4 d = *reinterpret_cast<const float4*>(ldp + (wv * C + ch) * 2);
-        const uint2 id = *reinterpret_cast<const uint2*>(lam + wv * C + ch);
-        v = pc_route8(d, id, (uint32_t)(((y & 1) << 1) | (x & 1)));
-      }
-      *reinterpret_cast<float4*>(dy + ((((int64_t)b * nblk + blk) * Hd + yy) * Wd + xx) * 16 + 8 * hf) = v;
-    }
-  }
-}
-
 // ------------------------------------------------------------------ weight gradient
 // dW[(tap, ci), co] = sum over pixels of x[pixel + tap][ci] * dY[pixel][co]: the reduction runs over pixels, so both MFMA
 // operands are reduction-major and reach the matrix cores through ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane
@@ -539,9 +592,10 @@ constexpr int PW_LDS = 2 * PW_STAGE;
 
 struct PwParams {
   const char* x; const char* x_end;       // C16 [B][Ci/16][H][W][16] bf16
-  const char* dy; const char* dy_end;     // C16 [B][Co/16][Hd][Wd][16] bf16
+  const char* dp;                          // pooled gradient, C16 [B][Co/16][Hp][Wp][16] bf16
+  const char* am;                          // arg-max bytes, C16 [B][Co/16][Hp][Wp][16]
   float* slabs;                            // [grid][9][64][128]
-  int B, H, W, Ci, Co, Hd, Wd;
+  int B, H, W, Ci, Co, Hp, Wp;
   int tiles_y, tiles_x, ntiles;            // 4 x 32-pixel tiles over the pool-covered map, per image / in all
   int roles_co, nroles;                    // Co / 128, (Ci / 64) * (Co / 128)
   int dbg;                                 // timing experiments only (VQA_PCONV_DBG): 2 = no DMA after the first stage, 4 = no MFMA
@@ -566,9 +620,11 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
   const uint32_t a_lane = (uint32_t)((2 * wci + grp) * PW_XB + (8 * h + q) * 32 + p4 * 8);
   const uint32_t b_lane = (uint32_t)(PW_X + (2 * wco + grp) * PW_DB + (8 * h + q) * 32 + p4 * 8);
 
-  // ---- DMA: the four waves of one half issue a whole stage (the halves take turns, as in pconv_kernel).  Wave w4 fetches block
-  // w4 of the x patch (7 pieces, gathered: 34 of a row's pixels) and blocks 2 w4, 2 w4 + 1 of the dY tile (4 pieces each = the
-  // tile's 4 rows, 32 pixels = 1 KiB contiguous each)
+  // ---- x patch by DMA: the four waves of one half issue a stage's patch (the halves take turns, as in pconv_kernel): wave w4
+  // fetches block w4 (7 pieces, gathered: 34 of a row's pixels).  The dY tile is ROUTED: thread (wave = block of 16 channels,
+  // lane = (pooled row, pooled column, 8-channel half)) loads 16 bytes of dP + 8 arg-max bytes of one of the 2 x 16 windows
+  // under the tile and writes the window's four pixels (pc_route8) -- the pre-pool gradient never exists in HBM.  Loads for
+  // stage q + 2 are issued during stage q, routed into the other buffer at the start of stage q + 1.
   const int half = wave >> 2, w4 = wave & 3;
   uint32_t xvoff[PW_XPC];
 #pragma unroll
@@ -577,11 +633,16 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
     const int row = px / PW_XRS, xx = px - row * PW_XRS;
     xvoff[i] = row < 6 ? (uint32_t)((row * P.W + xx) * 32 + (lane & 1) * 16) : BUF_OOB;
   }
-  const uint32_t dlane = (uint32_t)lane * 16u;
+  const int rt_prow = lane >> 5, rt_pcol = (lane >> 1) & 15, rt_hb = lane & 1;
+  const uint32_t rt_dst = (uint32_t)(PW_X + wave * PW_DB + (2 * rt_prow * 32 + 2 * rt_pcol) * 32 + rt_hb * 16);
+  float4 rt_d;
+  uint2 rt_a;
 
-  PcTile nxt, dlt;
+  PcTile nxt, dlt, rtt;
   nxt.decode(stream < P.ntiles ? stream : 0, P.tiles_y, P.tiles_x);
   dlt.decode(nstreams, P.tiles_y, P.tiles_x);
+  rtt = nxt;
+  int rt_count = 0;
   auto issue = [&](const PcTile& tp, int buf) {
     const int y0 = tp.ty * 4, x0 = tp.tx * 32;
     const char* xb = P.x + ((((int64_t)tp.img * (P.Ci / 16) + ci0 / 16 + w4) * P.H + y0) * P.W + x0) * 32;
@@ -591,16 +652,25 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
 #pragma unroll
     for (int i = 0; i < PW_XPC; ++i)
       lds_dma16(rx, st + w4 * PW_XB + i * 1024, xvoff[i], 0u);
+  };
+  auto rt_load = [&]() {         // ALWAYS two loads (the counted wait of the next stage relies on it); past the stream: zeros
+    const bool on = rt_count < my_tiles;
+    const int64_t plane = ((int64_t)rtt.img * (P.Co / 16) + co0 / 16 + wave) * P.Hp * P.Wp;
+    const uint32_t pbytes = (uint32_t)(P.Hp * P.Wp * 32);
+    const __amdgpu_buffer_rsrc_t rd = buf_rsrc(P.dp + plane * 32, pbytes), ra = buf_rsrc(P.am + plane * 16, pbytes >> 1);
+    const int py = rtt.ty * 2 + rt_prow, px = rtt.tx * 16 + rt_pcol;
+    const bool ok = on && py < P.Hp && px < P.Wp;
+    const uint32_t o = (uint32_t)((py * P.Wp + px) * 2 + rt_hb);
+    rt_d = buf_load16(rd, ok ? o * 16u : BUF_OOB);
+    rt_a = buf_load8(ra, ok ? o * 8u : BUF_OOB);
+    ++rt_count;
+    rtt.advance(dlt, P.tiles_y, P.tiles_x);
+  };
+  auto rt_route = [&](int buf) {
+    char* const dst = smem + buf * PW_STAGE + rt_dst;
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
-      const int blk = 2 * w4 + bb;
-      const char* db = P.dy + ((((int64_t)tp.img * (P.Co / 16) + co0 / 16 + blk) * P.Hd + y0 + 2) * P.Wd + x0 + 2) * 32;
-      const int64_t dl = P.dy_end - db;
-      const pc_rsrc_t rd = pc_rsrc(db, dl > 0xffff0000LL ? 0xffff0000u : (uint32_t)dl);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        lds_dma16(rd, st + PW_X + blk * PW_DB + rr * 1024, dlane, (uint32_t)(rr * P.Wd * 32));
-    }
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(dst + ((j >> 1) * 32 + (j & 1)) * 32) = pc_route8(rt_d, rt_a, (uint32_t)j);
   };
 
   f32x16 acc[9];
@@ -616,10 +686,16 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
     return __builtin_bit_cast(bf16x8, v);
   };
 
-  if (my_tiles > 0 && half == 1) issue(nxt, 0);
+  if (my_tiles > 0) {
+    if (half == 1) issue(nxt, 0);
+    rt_load();
+    rt_route(0);
+    rt_load();
+  }
   int buf = 0;
   for (int k = 0; k < my_tiles; ++k) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the x pieces of this stage have landed; the two routed loads issued after them (mid-stage) may still be in flight
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     nxt.advance(dlt, P.tiles_y, P.tiles_x);
     if (k + 1 < my_tiles && half == buf && !PC_DBG(2)) issue(nxt, buf ^ 1);
@@ -639,6 +715,16 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
         else asm volatile("" ::"v"(a[t]), "v"(b[s & 1]));
         if (s < 7)
           a[t] = frag(xa + ((((s + 1) >> 1) + t / 3) * PW_XRS + 16 * ((s + 1) & 1) + t % 3) * 32);
+      }
+      // the next stage's dY tile: routed from the registers loaded a stage ago (hipcc waits for those two loads: by now nothing
+      // older is in flight), then the loads for the stage after it.  The two waves of a SIMD do it at different k-steps, so the
+      // VALU / ds_write burst of one runs under the other's MFMAs -- the half that issued this stage's DMA pieces later (hipcc's
+      // wait for the two loads is a vmcnt(0): it would wait for pieces issued just before, too).
+      if (s == (half == (buf ^ (k & 0)) ? 5 : 2)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < my_tiles) rt_route(buf ^ 1);
+        rt_load();
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     buf ^= 1;
@@ -670,37 +756,36 @@ __global__ __launch_bounds__(256) void pconv_wgrad_reduce_kernel(const float* sl
 }
 
 // bias gradient = column sums of the pooled gradient over the windows that are alive (arg-max != 4); two deterministic stages.
-// A thread owns 8 consecutive channels (one 16-byte load of dP + 8 arg-max bytes per window), the Co / 8 threads of a window sit
-// side by side (coalesced NHWC rows), 256 / (Co / 8) window lanes per block stride over the block's windows and are combined
-// through LDS in a fixed order.
-__global__ __launch_bounds__(256) void pconv_bias_part_kernel(const uint16_t* dp, const uint8_t* am, float* part, int64_t windows,
-                                                             int Co, int64_t per) {
-  extern __shared__ __attribute__((aligned(16))) float bred[];      // [window lanes][Co]
-  const int cpr = Co / 8, nwl = 256 / cpr;
-  const int c = threadIdx.x % cpr, wl = threadIdx.x / cpr;
-  const int64_t w0 = (int64_t)blockIdx.x * per;
-  const int64_t w1 = w0 + per < windows ? w0 + per : windows;
+// dP and the arg-max bytes are C16: a block takes one (image, 16-channel block) plane chunk, a thread 8 channels of a window
+// (16 bytes of dP + 8 bytes) with consecutive threads on consecutive 16-byte pieces; the 128 threads of a half are combined
+// through LDS in a fixed order.  part[chunk][Co], chunk = image * chunks_per_plane + c.
+__global__ __launch_bounds__(256) void pconv_bias_part_kernel(const uint16_t* dp, const uint8_t* am, float* part, int plane,
+                                                             int Co, int cpp, int per) {
+  __shared__ float bred[256][9];
+  const int chunk = blockIdx.x % cpp, blk = (blockIdx.x / cpp) % (Co / 16), b = blockIdx.x / (cpp * (Co / 16));
+  const int hf = threadIdx.x & 1;
+  const int64_t base = ((int64_t)b * (Co / 16) + blk) * plane;
+  const int w1 = (chunk + 1) * per < plane ? (chunk + 1) * per : plane;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (wl < nwl) {
-    for (int64_t w = w0 + wl; w < w1; w += nwl) {
-      const uint4 d = *reinterpret_cast<const uint4*>(dp + w * Co + 8 * c);
-      const uint2 a = *reinterpret_cast<const uint2*>(am + w * Co + 8 * c);
-      const uint32_t dd[4] = {d.x, d.y, d.z, d.w};
+  for (int w = chunk * per + (threadIdx.x >> 1); w < w1; w += 128) {
+    const uint4 d = *reinterpret_cast<const uint4*>(dp + (base + w) * 16 + 8 * hf);
+    const uint2 a = *reinterpret_cast<const uint2*>(am + (base + w) * 16 + 8 * hf);
+    const uint32_t dd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t code = ((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xffu;
-        const float v = (k & 1) ? bf16_hi(dd[k >> 1]) : bf16_lo(dd[k >> 1]);
-        acc[k] += code != 4u ? v : 0.f;
-      }
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t code = ((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xffu;
+      const float v = (k & 1) ? bf16_hi(dd[k >> 1]) : bf16_lo(dd[k >> 1]);
+      acc[k] += code != 4u ? v : 0.f;
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bred[wl * Co + 8 * c + k] = acc[k];
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bred[threadIdx.x][k] = acc[k];
   __syncthreads();
-  for (int co = threadIdx.x; co < Co; co += 256) {
+  if (threadIdx.x < 16) {
+    const int c = threadIdx.x;                               // channel c of the block: half c / 8, element c % 8
     float s = 0.f;
-    for (int l = 0; l < nwl; ++l) s += bred[l * Co + co];
-    part[(int64_t)blockIdx.x * Co + co] = s;
+    for (int l = 0; l < 128; ++l) s += bred[2 * l + (c >> 3)][c & 7];
+    part[((int64_t)b * cpp + chunk) * Co + blk * 16 + c] = s;
   }
 }
 // dbias[co] = sum of the parts, in a fixed order: a block takes 32 channels, its 8 part lanes stride over the parts and
@@ -725,10 +810,10 @@ __global__ __launch_bounds__(256) void pconv_bias_reduce_kernel(const float* par
 // ------------------------------------------------------------------ host side
 static int pc_nslab(int N) { return N % 128 == 0 ? 128 : 64; }
 
-template <int WMv, int EPI>
+template <int WMv, int EPI, bool RT>
 static int pc_launch(const PcParams& P, hipStream_t s) {
   using C = PcCfg<WMv>;
-  auto kern = pconv_kernel<WMv, EPI>;
+  auto kern = pconv_kernel<WMv, EPI, RT>;
   int rc = ensure_dyn_smem(reinterpret_cast<const void*>(kern), C::LDS_ALL, "attr(pconv)");
   if (rc) return rc;
   int grid = 256;                                   // one workgroup per CU (120 KiB of LDS each)
@@ -737,6 +822,8 @@ static int pc_launch(const PcParams& P, hipStream_t s) {
   return check_hip(hipGetLastError(), "pconv launch");
 }
 
+// epi: 0 / 1 forward (pooled bf16 C16 / fp32 NHWC) from a C16 map; 2 / 3 / 4 backward-data (dX bf16 NHWC / fp32 NHWC / bf16 C16)
+// from the routed pooled gradient
 static int pc_run(PcParams P, int epi, hipStream_t s) {
   const int nslab = pc_nslab(P.N);
   const int TY = nslab == 128 ? 16 : 32;
@@ -749,9 +836,22 @@ static int pc_run(PcParams P, int epi, hipStream_t s) {
     const char* e = getenv("VQA_PCONV_DBG");
     P.dbg = e ? atoi(e) : 0;
   }
-  if (nslab == 128)
-    return epi == 0 ? pc_launch<4, 0>(P, s) : epi == 1 ? pc_launch<4, 1>(P, s) : epi == 2 ? pc_launch<4, 2>(P, s) : pc_launch<4, 3>(P, s);
-  return epi == 0 ? pc_launch<8, 0>(P, s) : epi == 1 ? pc_launch<8, 1>(P, s) : epi == 2 ? pc_launch<8, 2>(P, s) : pc_launch<8, 3>(P, s);
+  if (nslab == 128) {
+    switch (epi) {
+      case 0: return pc_launch<4, 0, false>(P, s);
+      case 1: return pc_launch<4, 1, false>(P, s);
+      case 2: return pc_launch<4, 2, true>(P, s);
+      case 3: return pc_launch<4, 3, true>(P, s);
+      default: return pc_launch<4, 4, true>(P, s);
+    }
+  }
+  switch (epi) {
+    case 0: return pc_launch<8, 0, false>(P, s);
+    case 1: return pc_launch<8, 1, false>(P, s);
+    case 2: return pc_launch<8, 2, true>(P, s);
+    case 3: return pc_launch<8, 3, true>(P, s);
+    default: return pc_launch<8, 4, true>(P, s);
+  }
 }
 
 }  // namespace vqa
@@ -811,86 +911,68 @@ int vqa_pconv_fwd(const void* x, const void* wf_img, const float* bias, void* po
   return pc_run(P, pooled_is_bf16 ? 0 : 1, s);
 }
 
-int vqa_pconv_dy_dims(int H, int W, int* Hd, int* Wd) {
-  VQA_REQUIRE(Hd && Wd && H >= 4 && W >= 4, "vqa_pconv_dy_dims: bad args");
-  const int Hp = (H - 2) / 2, Wp = (W - 2) / 2;
-  const int h1 = H + 2, h2 = (2 * Hp + 3) / 4 * 4 + 4;          // backward-data reads rows 0 .. H+1; weight-gradient tiles of 4 rows
-  const int w1 = W + 2, w2 = (2 * Wp + 31) / 32 * 32 + 4;       // ... and of 32 columns, plus the tap halo
-  *Hd = h1 > h2 ? h1 : h2;
-  *Wd = w1 > w2 ? w1 : w2;
-  return VQA_OK;
-}
-
-int vqa_pconv_expand_dy(const void* dpooled, const uint8_t* argmax, void* dy_pad, int B, int Hp, int Wp, int Hd, int Wd, int C,
-                        vqa_stream_t stream) {
-  VQA_REQUIRE(dpooled && argmax && dy_pad && B > 0 && C % 8 == 0 && 2 * Hp + 4 <= Hd && 2 * Wp + 4 <= Wd,
-              "vqa_pconv_expand_dy: bad args Hp=%d Wp=%d Hd=%d Wd=%d C=%d", Hp, Wp, Hd, Wd, C);
-  VQA_REQUIRE(C % 16 == 0 && C <= 2048, "vqa_pconv_expand_dy: C=%d must be a multiple of 16, at most 2048", C);
-  const int64_t items = (int64_t)B * Hd * ((Wd + 31) / 32);
-  const int64_t blocks = items < 256 * 16 ? items : 256 * 16;
-  hipLaunchKernelGGL(pconv_expand_dy_kernel, dim3((unsigned)blocks), dim3(256), (size_t)17 * C * 3, (hipStream_t)stream,
-                     static_cast<const uint16_t*>(dpooled), argmax, static_cast<uint16_t*>(dy_pad), B, Hp, Wp, Hd, Wd, C);
-  return check_hip(hipGetLastError(), "pconv_expand_dy launch");
-}
-
-int vqa_pconv_dgrad(const void* dy_pad, int Hd, int Wd, const void* wd_img, void* dx, int dx_is_bf16, int B, int H, int W, int Ci,
-                    int Co, int tag, vqa_stream_t stream) {
-  VQA_REQUIRE(dy_pad && wd_img && dx && B > 0, "vqa_pconv_dgrad: null pointer");
-  VQA_REQUIRE(Hd >= H + 2 && Wd >= W + 2, "vqa_pconv_dgrad: dy_pad %dx%d is smaller than (H+2)x(W+2)", Hd, Wd);
+int vqa_pconv_dgrad(const void* dpooled, const uint8_t* argmax, const void* wd_img, void* dx, int dx_mode, int B, int H, int W,
+                    int Ci, int Co, int tag, vqa_stream_t stream) {
+  VQA_REQUIRE(dpooled && argmax && wd_img && dx && B > 0, "vqa_pconv_dgrad: null pointer");
+  VQA_REQUIRE(dx_mode >= 0 && dx_mode <= 2, "vqa_pconv_dgrad: dx_mode %d (0 fp32 NHWC, 1 bf16 NHWC, 2 bf16 C16)", dx_mode);
   VQA_REQUIRE(vqa_pconv_supported(H, W, Ci, Co, 1) && Ci % 64 == 0,
               "vqa_pconv_dgrad: unsupported shape H=%d W=%d Ci=%d Co=%d", H, W, Ci, Co);
   PcParams P{};
-  P.x = static_cast<const char*>(dy_pad);                   // [B][Hd][Wd][Co]: the padded pre-pool gradient
-  P.x_end = P.x + (int64_t)B * Hd * Wd * Co * 2;
+  P.x = static_cast<const char*>(dpooled);                  // C16 [B][Co/16][Hq][Wq][16]: the patches are routed from it
+  P.am_in = reinterpret_cast<const char*>(argmax);
+  P.Hq = (H - 2) / 2; P.Wq = (W - 2) / 2;
+  VQA_REQUIRE(P.Hq > 0 && P.Wq > 0, "vqa_pconv_dgrad: image too small");
+  P.x_end = P.x + (int64_t)B * P.Hq * P.Wq * Co * 2;
   P.wimg = static_cast<const char*>(wd_img);
   P.out = dx;
-  P.B = B; P.H = Hd; P.W = Wd; P.Cin = Co; P.N = Ci;
+  P.B = B; P.H = H + 2; P.W = W + 2; P.Cin = Co; P.N = Ci;   // the (virtual) padded pre-pool gradient map
   P.Hc = H; P.Wc = W;
   hipStream_t s = (hipStream_t)stream;
   set_launch_tag(tag);
   ProfScope prof(VQA_K_CONV_DGRAD, s);
-  return pc_run(P, dx_is_bf16 ? 2 : 3, s);
+  return pc_run(P, dx_mode == 0 ? 3 : dx_mode == 1 ? 2 : 4, s);
 }
 
 static int pw_roles(int Ci, int Co) { return (Ci / 64) * (Co / 128); }
-static int pw_bias_parts(int64_t windows) { int64_t p = (windows + 63) / 64; return (int)(p > 1024 ? 1024 : (p < 1 ? 1 : p)); }
+// chunks per (image, 16-channel block) plane of the bias-gradient partial sums
+static int pw_bias_cpp(int B, int Co, int plane) {
+  int cpp = 2048 / (B * (Co / 16));
+  const int most = (plane + 127) / 128;
+  if (cpp > most) cpp = most;
+  return cpp < 1 ? 1 : cpp;
+}
 
 int vqa_pconv_wgrad_supported(int H, int W, int Ci, int Co) {
   if (H < 4 || W < 4 || Ci <= 0 || Co <= 0 || Ci % 64 || Co % 128) return 0;
   const int r = pw_roles(Ci, Co);
   if (r != 1 && r != 2 && r != 4 && r != 8) return 0;
-  int Hd = 0, Wd = 0;
-  vqa_pconv_dy_dims(H, W, &Hd, &Wd);
-  if ((int64_t)8 * (W > Wd ? W : Wd) * (Ci > Co ? Ci : Co) * 2 >= (1LL << 31)) return 0;
+  if ((int64_t)8 * (W + 34) * (Ci > Co ? Ci : Co) * 2 >= (1LL << 31)) return 0;
   return 1;
 }
 
 int64_t vqa_pconv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co) {
   if (!vqa_pconv_wgrad_supported(H, W, Ci, Co) || B <= 0) return 0;
-  const int64_t windows = (int64_t)B * ((H - 2) / 2) * ((W - 2) / 2);
-  return ((int64_t)256 * 9 * 64 * 128 + (int64_t)pw_bias_parts(windows) * Co) * 4;
+  const int plane = ((H - 2) / 2) * ((W - 2) / 2);
+  return ((int64_t)256 * 9 * 64 * 128 + (int64_t)B * pw_bias_cpp(B, Co, plane) * Co) * 4;
 }
 
-int vqa_pconv_wgrad(const void* x, const void* dy_pad, int Hd, int Wd, const void* dpooled, const uint8_t* argmax, float* dw,
-                    float* dbias, int B, int H, int W, int Ci, int Co, float* workspace, int64_t workspace_bytes, int tag,
-                    vqa_stream_t stream) {
-  VQA_REQUIRE(x && dy_pad && dpooled && argmax && dw && dbias && workspace && B > 0, "vqa_pconv_wgrad: null pointer");
+int vqa_pconv_wgrad(const void* x, const void* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W,
+                    int Ci, int Co, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream) {
+  VQA_REQUIRE(x && dpooled && argmax && dw && dbias && workspace && B > 0, "vqa_pconv_wgrad: null pointer");
   VQA_REQUIRE(vqa_pconv_wgrad_supported(H, W, Ci, Co), "vqa_pconv_wgrad: unsupported shape H=%d W=%d Ci=%d Co=%d", H, W, Ci, Co);
   VQA_REQUIRE(Co <= 2048, "vqa_pconv_wgrad: Co=%d above 2048", Co);
-  int Hm = 0, Wm = 0;
-  vqa_pconv_dy_dims(H, W, &Hm, &Wm);
-  VQA_REQUIRE(Hd >= Hm && Wd >= Wm, "vqa_pconv_wgrad: dy_pad %dx%d is smaller than vqa_pconv_dy_dims (%dx%d)", Hd, Wd, Hm, Wm);
   const int64_t need = vqa_pconv_wgrad_workspace_bytes(B, H, W, Ci, Co);
   if (workspace_bytes < need) {
     set_error("vqa_pconv_wgrad: workspace %lld < %lld", (long long)workspace_bytes, (long long)need);
     return VQA_ERR_WORKSPACE;
   }
+  const int Hp = (H - 2) / 2, Wp = (W - 2) / 2;
+  VQA_REQUIRE(Hp > 0 && Wp > 0, "vqa_pconv_wgrad: image too small");
   PwParams P{};
   P.x = static_cast<const char*>(x); P.x_end = P.x + (int64_t)B * H * W * Ci * 2;
-  P.dy = static_cast<const char*>(dy_pad); P.dy_end = P.dy + (int64_t)B * Hd * Wd * Co * 2;
+  P.dp = static_cast<const char*>(dpooled); P.am = reinterpret_cast<const char*>(argmax);
   P.slabs = workspace;
-  P.B = B; P.H = H; P.W = W; P.Ci = Ci; P.Co = Co; P.Hd = Hd; P.Wd = Wd;
-  const int Hp = (H - 2) / 2, Wp = (W - 2) / 2;
+  P.B = B; P.H = H; P.W = W; P.Ci = Ci; P.Co = Co; P.Hp = Hp; P.Wp = Wp;
   P.tiles_y = (2 * Hp + 3) / 4; P.tiles_x = (2 * Wp + 31) / 32;
   P.ntiles = B * P.tiles_y * P.tiles_x;
   P.roles_co = Co / 128; P.nroles = pw_roles(Ci, Co);
@@ -911,15 +993,13 @@ int vqa_pconv_wgrad(const void* x, const void* dy_pad, int Hd, int Wd, const voi
                      P.nroles, P.roles_co);
   rc = check_hip(hipGetLastError(), "pconv_wgrad_reduce launch");
   if (rc) return rc;
-  const int64_t windows = (int64_t)B * Hp * Wp;
-  const int parts = pw_bias_parts(windows);
-  const int64_t per = (windows + parts - 1) / parts;
+  const int plane = Hp * Wp, cpp = pw_bias_cpp(B, Co, plane), per = (plane + cpp - 1) / cpp;
   float* const bpart = workspace + (int64_t)256 * 9 * 64 * 128;
-  hipLaunchKernelGGL(pconv_bias_part_kernel, dim3(parts), dim3(256), (size_t)(256 / (Co / 8)) * Co * 4, s,
-                     static_cast<const uint16_t*>(dpooled), argmax, bpart, windows, Co, per);
+  hipLaunchKernelGGL(pconv_bias_part_kernel, dim3(B * (Co / 16) * cpp), dim3(256), 0, s, static_cast<const uint16_t*>(dpooled),
+                     argmax, bpart, plane, Co, cpp, per);
   rc = check_hip(hipGetLastError(), "pconv_bias_part launch");
   if (rc) return rc;
-  hipLaunchKernelGGL(pconv_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bpart, dbias, parts, Co);
+  hipLaunchKernelGGL(pconv_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bpart, dbias, B * cpp, Co);
   return check_hip(hipGetLastError(), "pconv_bias_reduce launch");
 }
 

@@ -109,10 +109,12 @@ __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, i
   }
 }
 
-// OB: the gradient is stored as bf16 (bf16 path: it is the pooled gradient of the last conv block, staged as bf16 anyway)
-template <bool OB>
+// OB 1 / 2: the gradient is stored as bf16 (bf16 path: it is the pooled gradient of the last conv block, staged as bf16 anyway);
+// 2: channel-blocked [image][C/16][position][16] -- what the routed patches of the patch convolutions read (a lane's 4
+// channels are 8 bytes of one block; the four rows of a workgroup are consecutive positions = 128 contiguous bytes per block)
+template <int OB>
 __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float* norm, void* dpooled_,
-                                  int64_t rows, int C, float p, float inv_keep, uint64_t seed) {
+                                  int64_t rows, int C, float p, float inv_keep, uint64_t seed, int positions) {
   float* const dpooled = static_cast<float*>(dpooled_);
   uint16_t* const dpooled16 = static_cast<uint16_t*>(dpooled_);
   const int lane = threadIdx.x & 63;
@@ -143,7 +145,13 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
       if (OB) {
         typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
         const bf2 lo = {(__bf16)d.x, (__bf16)d.y}, hi = {(__bf16)d.z, (__bf16)d.w};
-        dst16[c] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+        const uint2 o = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+        if (OB == 2) {
+          const int64_t img = r / positions, pos = r - img * positions;
+          *reinterpret_cast<uint2*>(dpooled16 + ((img * (C >> 4) + (c >> 2)) * positions + pos) * 16 + (c & 3) * 4) = o;
+        } else {
+          dst16[c] = o;
+        }
       } else {
         dst[c] = d;
       }
@@ -823,17 +831,22 @@ int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, in
   return check_hip(hipGetLastError(), "l2norm_fwd launch");
 }
 
-int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, void* dpooled, int dpooled_is_bf16, int64_t rows,
-                   int C, float p, uint64_t seed, vqa_stream_t stream) {
+int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, void* dpooled, int dpooled_mode, int64_t rows,
+                   int positions, int C, float p, uint64_t seed, vqa_stream_t stream) {
   set_launch_tag(-1);
   ProfScope prof(VQA_K_L2NORM_BWD, (hipStream_t)stream);
-  VQA_REQUIRE(dvn && vn && norm && dpooled && rows > 0 && C % 4 == 0, "vqa_l2norm_bwd: bad args");
-  if (dpooled_is_bf16)
-    hipLaunchKernelGGL(l2norm_bwd_kernel<true>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
-                       C, p, KEEP(p), seed);
+  VQA_REQUIRE(dvn && vn && norm && dpooled && rows > 0 && C % 4 == 0 && dpooled_mode >= 0 && dpooled_mode <= 2, "vqa_l2norm_bwd: bad args");
+  VQA_REQUIRE(dpooled_mode != 2 || (C % 16 == 0 && positions > 0 && rows % positions == 0),
+              "vqa_l2norm_bwd: the channel-blocked output needs C %% 16 == 0 and rows = images x positions (C=%d, positions=%d)", C, positions);
+  if (dpooled_mode == 2)
+    hipLaunchKernelGGL(l2norm_bwd_kernel<2>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
+                       C, p, KEEP(p), seed, positions);
+  else if (dpooled_mode == 1)
+    hipLaunchKernelGGL(l2norm_bwd_kernel<1>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
+                       C, p, KEEP(p), seed, positions);
   else
-    hipLaunchKernelGGL(l2norm_bwd_kernel<false>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
-                       C, p, KEEP(p), seed);
+    hipLaunchKernelGGL(l2norm_bwd_kernel<0>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
+                       C, p, KEEP(p), seed, positions);
   return check_hip(hipGetLastError(), "l2norm_bwd launch");
 }
 

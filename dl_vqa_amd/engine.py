@@ -580,8 +580,11 @@ class Engine:
             main.wait_event(ev0)
 
         # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first
-        dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE),
-                            out_dtype=torch.bfloat16 if self.bf16 else torch.float32).view_as(ctx.acts[-1])
+        if self.bf16 and ctx.use_pc:      # channel-blocked, as the routed patches of the backward kernels read it
+            dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE), c16_hw=tuple(ctx.idxs[-1].shape[2:4]))
+        else:
+            dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE),
+                                out_dtype=torch.bfloat16 if self.bf16 else torch.float32).view_as(ctx.acts[-1])
         for l in range(self.L - 1, -1, -1):
             if l == 0 and ctx.fast0:
                 if self.bf16:
@@ -590,13 +593,11 @@ class Engine:
                     ops.conv0_wgrad(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])
                 continue
             if self.bf16 and ctx.use_pc:
-                # the pre-pool gradient is materialised once per block (routed by the arg-max bytes, C16, zero-padded):
-                # weight gradient and backward-data both read it as a plain operand
+                # both kernels route the pre-pool gradient themselves (pooled gradient + arg-max bytes, C16); the block below
+                # gets its pooled gradient C16 again, the first block's weight gradient NHWC
                 Bx, _, Hx, Wx, _ = ctx.acts[l].shape
-                dyp = ops.pconv_expand_dy(dP, ctx.idxs[l], Hx, Wx)
-                ops.pconv_wgrad(ctx.acts[l], dyp, dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"], tag=l)
-                dP = ops.pconv_dgrad(dyp, ctx.wds[l], (Bx, Hx, Wx, self.channels[l]), tag=l)
-                del dyp
+                ops.pconv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"], tag=l)
+                dP = ops.pconv_dgrad(dP, ctx.idxs[l], ctx.wds[l], (Bx, Hx, Wx, self.channels[l]), out_c16=l > 1, tag=l)
                 continue
             if self.bf16:
                 ops.conv_wgrad_bf16(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],

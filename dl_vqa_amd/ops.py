@@ -238,12 +238,19 @@ def l2norm_fwd(pooled: torch.Tensor, p: float, seed: int, drop2=None):
     return vn, norm, vd
 
 
-def l2norm_bwd(dvn, vn, norm, p: float, seed: int, out=None, out_dtype=torch.float32):
-    """out_dtype=torch.bfloat16: the gradient is stored as bf16 (the bf16 path's pooled gradient of the last conv block)."""
+def l2norm_bwd(dvn, vn, norm, p: float, seed: int, out=None, out_dtype=torch.float32, c16_hw=None):
+    """out_dtype=torch.bfloat16: the gradient is stored as bf16 (the bf16 path's pooled gradient of the last conv block);
+    c16_hw=(Hp, Wp): bf16, channel-blocked [B, C/16, Hp, Wp, 16] (what the patch convolutions' backward kernels read)."""
     C = vn.shape[-1]
+    rows = vn.numel() // C
+    if c16_hw is not None:
+        Hp, Wp = c16_hw
+        assert out is None and rows % (Hp * Wp) == 0 and C % 16 == 0
+        d = torch.empty(rows // (Hp * Wp), C // 16, Hp, Wp, 16, dtype=torch.bfloat16, device=vn.device)
+        call("vqa_l2norm_bwd", ptr(dvn), ptr(vn), ptr(norm), ptr(d), 2, rows, Hp * Wp, C, p, seed, stream())
+        return d
     d = out if out is not None else torch.empty(vn.shape, dtype=out_dtype, device=vn.device)
-    call("vqa_l2norm_bwd", ptr(dvn), ptr(vn), ptr(norm), ptr(d), int(d.dtype == torch.bfloat16), vn.numel() // C, C, p, seed,
-         stream())
+    call("vqa_l2norm_bwd", ptr(dvn), ptr(vn), ptr(norm), ptr(d), int(d.dtype == torch.bfloat16), rows, 0, C, p, seed, stream())
     return d
 
 
@@ -543,7 +550,7 @@ def pconv_pack_weights(w: torch.Tensor, need_wd: bool = True):
 
 
 def pconv_fwd(x: torch.Tensor, wf_img: torch.Tensor, bias: torch.Tensor, Co: int, out_dtype=torch.bfloat16, tag: int = 0):
-    """x C16 bf16 [B,Ci/16,H,W,16] -> (pooled: bf16 C16 [B,Co/16,Hp,Wp,16] or fp32 NHWC [B,Hp,Wp,Co]; argmax uint8 NHWC)."""
+    """x C16 bf16 [B,Ci/16,H,W,16] -> (pooled: bf16 C16 [B,Co/16,Hp,Wp,16] or fp32 NHWC [B,Hp,Wp,Co]; argmax uint8 C16)."""
     assert x.dtype == torch.bfloat16 and wf_img.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 5
     B, Cb, H, W, _ = x.shape
     Hp, Wp = conv_out_hw(H, W, 1)
@@ -551,39 +558,29 @@ def pconv_fwd(x: torch.Tensor, wf_img: torch.Tensor, bias: torch.Tensor, Co: int
         pooled = torch.empty(B, Co // 16, Hp, Wp, 16, dtype=torch.bfloat16, device=x.device)
     else:
         pooled = torch.empty(B, Hp, Wp, Co, dtype=out_dtype, device=x.device)
-    amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x.device)
+    amax = torch.empty(B, Co // 16, Hp, Wp, 16, dtype=torch.uint8, device=x.device)
     call("vqa_pconv_fwd", ptr(x), ptr(wf_img), ptr(bias), ptr(pooled), int(out_dtype == torch.bfloat16), ptr(amax),
          B, H, W, Cb * 16, Co, tag, stream())
     return pooled, amax
 
 
-def pconv_dy_dims(H: int, W: int):
-    """(Hd, Wd) of the materialised pre-pool gradient of a block whose INPUT map is H x W."""
-    import ctypes
-    hd, wd = ctypes.c_int(), ctypes.c_int()
-    call("vqa_pconv_dy_dims", H, W, ctypes.byref(hd), ctypes.byref(wd))
-    return hd.value, wd.value
-
-
-def pconv_expand_dy(dpooled: torch.Tensor, amax: torch.Tensor, H: int, W: int):
-    """Pooled gradient bf16 NHWC [B,Hp,Wp,C] + arg-max bytes -> the pre-pool gradient of the block with input map H x W,
-    routed, bf16 C16 [B,C/16,Hd,Wd,16] with dY(y, x) at (y+2, x+2) and zeros elsewhere (what pconv_dgrad / pconv_wgrad read)."""
-    assert dpooled.dtype == torch.bfloat16 and dpooled.is_contiguous()
-    B, Hp, Wp, C = dpooled.shape
-    Hd, Wd = pconv_dy_dims(H, W)
-    dy = torch.empty(B, C // 16, Hd, Wd, 16, dtype=torch.bfloat16, device=dpooled.device)
-    call("vqa_pconv_expand_dy", ptr(dpooled), ptr(amax), ptr(dy), B, Hp, Wp, Hd, Wd, C, stream())
-    return dy
-
-
-def pconv_dgrad(dy_pad: torch.Tensor, wd_img: torch.Tensor, x_shape, out_dtype=torch.bfloat16, tag: int = 0):
-    """dy_pad C16 -> dX NHWC [B,H,W,Ci] (bf16 or fp32); x_shape = (B, H, W, Ci) of the block's input."""
+def pconv_dgrad(dpooled: torch.Tensor, amax: torch.Tensor, wd_img: torch.Tensor, x_shape, out_dtype=torch.bfloat16,
+                out_c16: bool = False, tag: int = 0):
+    """Pooled gradient (bf16 C16 [B,Co/16,Hp,Wp,16]) + arg-max bytes (C16) -> dX of the block whose input is x_shape =
+    (B, H, W, Ci): NHWC (bf16 or fp32), or bf16 C16 (the pooled gradient of the block below).  The pre-pool gradient is routed
+    inside the kernel."""
     B, H, W, Ci = x_shape
-    _, Cb, Hd, Wd, _ = dy_pad.shape
-    assert dy_pad.dtype == torch.bfloat16 and dy_pad.shape[0] == B
-    dx = torch.empty(B, H, W, Ci, dtype=out_dtype, device=dy_pad.device)
-    call("vqa_pconv_dgrad", ptr(dy_pad), Hd, Wd, ptr(wd_img), ptr(dx), int(out_dtype == torch.bfloat16), B, H, W, Ci, Cb * 16,
-         tag, stream())
+    assert dpooled.dtype == torch.bfloat16 and dpooled.dim() == 5 and dpooled.is_contiguous() and dpooled.shape[0] == B
+    assert amax.dtype == torch.uint8 and amax.shape == dpooled.shape and amax.is_contiguous()
+    assert tuple(dpooled.shape[2:4]) == conv_out_hw(H, W, 1)
+    Co = dpooled.shape[1] * 16
+    if out_c16:
+        assert out_dtype == torch.bfloat16
+        dx = torch.empty(B, Ci // 16, H, W, 16, dtype=torch.bfloat16, device=dpooled.device)
+    else:
+        dx = torch.empty(B, H, W, Ci, dtype=out_dtype, device=dpooled.device)
+    mode = 2 if out_c16 else int(out_dtype == torch.bfloat16)
+    call("vqa_pconv_dgrad", ptr(dpooled), ptr(amax), ptr(wd_img), ptr(dx), mode, B, H, W, Ci, Co, tag, stream())
     return dx
 
 
@@ -591,17 +588,17 @@ def pconv_wgrad_supported(H: int, W: int, Ci: int, Co: int) -> bool:
     return bool(_lib.load().vqa_pconv_wgrad_supported(H, W, Ci, Co))
 
 
-def pconv_wgrad(x, dy_pad, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, tag: int = 0):
-    """dw [Co,Ci,3,3], dbias [Co] (fp32) from x (C16 bf16), the materialised pre-pool gradient (C16) and, for the bias, the
-    pooled gradient + arg-max bytes (NHWC)."""
-    assert x.dtype == torch.bfloat16 and dy_pad.dtype == torch.bfloat16 and dpooled.dtype == torch.bfloat16
+def pconv_wgrad(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, tag: int = 0):
+    """dw [Co,Ci,3,3], dbias [Co] (fp32) from x (C16 bf16), the pooled gradient (C16 bf16) and the arg-max bytes (C16)."""
+    assert x.dtype == torch.bfloat16 and dpooled.dtype == torch.bfloat16 and amax.dtype == torch.uint8
+    assert x.is_contiguous() and dpooled.is_contiguous() and amax.is_contiguous() and amax.shape == dpooled.shape
     lib = _lib.load()
     B, Cib, H, W, _ = x.shape
-    _, Cob, Hd, Wd, _ = dy_pad.shape
-    Ci, Co = Cib * 16, Cob * 16
+    Ci, Co = Cib * 16, dpooled.shape[1] * 16
+    assert tuple(dpooled.shape[2:4]) == conv_out_hw(H, W, 1) and dpooled.shape[0] == B
     ws = workspace(lib.vqa_pconv_wgrad_workspace_bytes(B, H, W, Ci, Co), x.device)
-    call("vqa_pconv_wgrad", ptr(x), ptr(dy_pad), Hd, Wd, ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, Ci, Co,
-         ptr(ws), ws.numel() * 4, tag, stream())
+    call("vqa_pconv_wgrad", ptr(x), ptr(dpooled), ptr(amax), ptr(dw), ptr(dbias), B, H, W, Ci, Co, ptr(ws), ws.numel() * 4, tag,
+         stream())
 
 
 def scale_by(x, scalar_dev):

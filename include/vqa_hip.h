@@ -28,7 +28,7 @@ extern "C" {
 
 /* Bumped whenever an exported entry point changes its argument list or disappears (round 1: 1, round 2: 2, round 3: 3).
  * dl_vqa_amd/_lib.py parses this line and refuses a library that answers differently. */
-#define VQA_ABI_VERSION 3
+#define VQA_ABI_VERSION 4
 
 #define VQA_OK 0
 #define VQA_ERR_INVALID 1 /* bad argument (shape, alignment, null pointer) */
@@ -151,8 +151,10 @@ int vqa_dropout_add(const float* x, float* y, int64_t n, float p, uint64_t seed,
 int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, int C, float p,
                    uint64_t seed, void* vdrop, int vdrop_is_bf16, float p2, uint64_t seed2, vqa_stream_t stream);
 int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, void* dpooled,
-                   int dpooled_is_bf16 /* bf16 path: the gradient is stored as bf16 (no separate conversion pass) */,
-                   int64_t rows, int C, float p, uint64_t seed, vqa_stream_t stream);
+                   int dpooled_mode /* 0 fp32 [rows][C]; 1 bf16 [rows][C] (bf16 path: no separate conversion pass); 2 bf16
+                                       channel-blocked [rows / positions][C/16][positions][16] for vqa_pconv_dgrad / _wgrad */,
+                   int64_t rows, int positions /* rows per image: mode 2 only */, int C, float p, uint64_t seed,
+                   vqa_stream_t stream);
 
 /* ---- question encoder (models/model.py:134-166 questionNet) ----------------------------------
  * x[t][b][:] = tanh(dropout(emb[q[b][t]]))   (embedding -> drop -> tanh, model.py:155-157).
@@ -316,35 +318,37 @@ int vqa_conv3x3_wgrad_bf16(const void* x, const void* dpooled, const uint8_t* ar
                            int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
 /* Patch convolutions of the bf16 path (csrc/conv_patch_bf16.hip; models/model.py:80-82 and their autograd), 3x3, stride 1:
- * a persistent workgroup keeps an input patch in LDS (filled by buffer_load ... lds) and takes the nine taps as shifted
- * fragment reads of it, so every input pixel is fetched once per workgroup instead of once per tap.  Same tensors and
- * results contract as the vqa_conv3x3_*_bf16 entry points (activations NHWC bf16, arg-max bytes, fp32 accumulation), with two
- * differences: the weights are packed per step into fragment-ordered images (vqa_pconv_pack_weights; wf_img for forward,
- * wd_img = flipped + transposed for backward-data, vqa_pconv_weights_bytes each), and the backward kernels read the
- * pre-pool gradient MATERIALISED once per layer: dy_pad [B][Hd][Wd][Co] bf16 with dY(y, x) at (y+2, x+2), routed by the
- * arg-max bytes, zero everywhere else (vqa_pconv_expand_dy; Hd x Wd from vqa_pconv_dy_dims: at least (H+2) x (W+2), padded
- * so that the weight-gradient tiles may overhang the map), so that backward-data is a plain valid convolution of dy_pad.
+ * a persistent workgroup keeps an input patch in LDS and takes the nine taps as shifted fragment reads of it, so every
+ * input pixel is fetched once per workgroup instead of once per tap.  Same results contract as the vqa_conv3x3_*_bf16 entry
+ * points (bf16 operands, fp32 accumulation, arg-max codes 0-3 / 4 = dead window); what differs:
+ *   - every tensor a patch is cut from is channel-blocked "C16": [B][C/16][H][W][16] -- the activations between the blocks
+ *     (bf16), the pooled gradients (bf16) AND the arg-max bytes;
+ *   - the weights are packed per step into fragment-ordered images (vqa_pconv_pack_weights; wf_img for forward, wd_img =
+ *     flipped + transposed for backward-data, vqa_pconv_weights_bytes each);
+ *   - forward patches are copied by buffer_load ... lds; backward patches (the pre-pool gradient: dP where the arg-max byte
+ *     names the pixel, zero elsewhere and on the border) are ROUTED in the kernel from dP + arg-max -- the pre-pool
+ *     gradient, four times the pooled one, never exists in HBM.
  * Shapes: Ci % 16 == 0, Co % 64 == 0 (forward); additionally Ci % 64 == 0 for backward-data (vqa_pconv_supported). */
 int vqa_pconv_supported(int H, int W, int Ci, int Co, int stride);
 int64_t vqa_pconv_weights_bytes(int Ci, int Co);
 int vqa_pconv_pack_weights(const float* w /* [Co][Ci][3][3] */, void* wf_img /* may be NULL */, void* wd_img /* may be NULL */,
                            int Co, int Ci, vqa_stream_t stream);
+/* x C16 [B][Ci/16][H][W][16] -> pooled (bf16 C16 [B][Co/16][Hp][Wp][16] or fp32 NHWC [B][Hp][Wp][Co]) and arg-max bytes
+ * (always C16 [B][Co/16][Hp][Wp][16]) */
 int vqa_pconv_fwd(const void* x, const void* wf_img, const float* bias, void* pooled, int pooled_is_bf16, uint8_t* argmax,
                   int B, int H, int W, int Ci, int Co, int tag, vqa_stream_t stream);
-int vqa_pconv_dy_dims(int H, int W, int* Hd, int* Wd); /* H, W: the block's INPUT map */
-int vqa_pconv_expand_dy(const void* dpooled, const uint8_t* argmax, void* dy_pad, int B, int Hp, int Wp, int Hd, int Wd,
-                        int C, vqa_stream_t stream);
-int vqa_pconv_dgrad(const void* dy_pad, int Hd, int Wd, const void* wd_img, void* dx, int dx_is_bf16, int B, int H, int W,
+/* dX of the block whose INPUT map is H x W x Ci, from the pooled gradient and arg-max bytes (both C16, [B][Co/16][Hp][Wp][16]).
+ * dx_mode: 0 fp32 NHWC, 1 bf16 NHWC (feeds vqa_conv0_wgrad_bf16), 2 bf16 C16 (the pooled gradient of the block below) */
+int vqa_pconv_dgrad(const void* dpooled, const uint8_t* argmax, const void* wd_img, void* dx, int dx_mode, int B, int H, int W,
                     int Ci, int Co, int tag, vqa_stream_t stream);
 /* weight + bias gradient: dw [Co][Ci][3][3], dbias [Co] fp32.  A workgroup holds a whole [9 taps x 64 ci] x [128 co] block of
- * dW in its accumulators and streams 4 x 32-pixel tiles of x (LDS patch, nine shifted transpose-reads) and dy_pad through
- * LDS; one fp32 slab per workgroup, summed by a reduce kernel (deterministic).  Ci % 64 == 0, Co % 128 == 0, and
- * (Ci / 64) * (Co / 128) in {1, 2, 4, 8}; dbias is the masked column sum of dpooled (arg-max != 4). */
+ * dW in its accumulators and streams 4 x 32-pixel tiles of x (C16; LDS patch, nine shifted transpose-reads) and of the routed
+ * pre-pool gradient through LDS; one fp32 slab per workgroup, summed by a reduce kernel (deterministic).  Ci % 64 == 0,
+ * Co % 128 == 0, and (Ci / 64) * (Co / 128) in {1, 2, 4, 8}; dbias is the masked sum of dpooled (arg-max != 4). */
 int vqa_pconv_wgrad_supported(int H, int W, int Ci, int Co);
 int64_t vqa_pconv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co);
-int vqa_pconv_wgrad(const void* x, const void* dy_pad, int Hd, int Wd, const void* dpooled, const uint8_t* argmax, float* dw,
-                    float* dbias, int B, int H, int W, int Ci, int Co, float* workspace, int64_t workspace_bytes, int tag,
-                    vqa_stream_t stream);
+int vqa_pconv_wgrad(const void* x, const void* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W,
+                    int Ci, int Co, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
 
 /* ---- fp32 on the bf16 matrix cores ("fp32x3": csrc/x3_core.hpp) -------------------------------
  * The same fp32 tensors, layouts and results contract as the fp32 entry points above; inside the K loop every

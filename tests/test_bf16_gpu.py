@@ -419,8 +419,8 @@ def test_bf16_path_rejects_unsupported_configs():
                                          (1, 70, 45, 16, 64), (2, 37, 75, 128, 128), (5, 18, 100, 32, 256)])
 def test_pconv_fwd_dgrad_wgrad(B, H, W, Ci, Co):
     """csrc/conv_patch_bf16.hip against float64 autograd on bf16-rounded x, w, dy: forward (fp32 NHWC and bf16 C16 outputs,
-    arg-max), the materialised pre-pool gradient (bit-exact routing, zero border and padding, C16), backward-data (fp32 and
-    bf16 outputs), weight + bias gradient.  Shapes with tile overhang on both axes, odd sizes (dropped pool row / column),
+    arg-max C16), backward-data with the pre-pool gradient routed in the kernel (fp32 / bf16 NHWC and bf16 C16 outputs: zero
+    border, dropped pool rows / columns, dead windows), weight + bias gradient.  Shapes with tile overhang on both axes, odd sizes (dropped pool row / column),
     one and several 64-/128-channel slabs and roles, several images (persistent tile streams that cross image borders)."""
     ops = _ops()
     assert ops.pconv_supported(H, W, Ci, Co)
@@ -437,12 +437,15 @@ def test_pconv_fwd_dgrad_wgrad(B, H, W, Ci, Co):
     xc = ops.to_c16(xd)                                                        # what the patch kernels read
     assert torch.equal(ops.from_c16(xc), xd)
     wf, wd = ops.pconv_pack_weights(w.to(DEV), need_wd=Ci % 64 == 0)
-    p32, amax = ops.pconv_fwd(xc, wf, b.to(DEV), Co, out_dtype=torch.float32)
+    p32, amax16 = ops.pconv_fwd(xc, wf, b.to(DEV), Co, out_dtype=torch.float32)
     p16, amax2 = ops.pconv_fwd(xc, wf, b.to(DEV), Co)
     torch.cuda.synchronize()
     tag = f"{B,H,W,Ci,Co}"
+    Hp, Wp = yr.shape[2], yr.shape[3]
+    assert tuple(amax16.shape) == (B, Co // 16, Hp, Wp, 16)              # arg-max bytes are channel-blocked like the activations
+    amax = ops.from_c16(amax16)
     check(f"pconv fwd fp32-out {tag}", p32.permute(0, 3, 1, 2), yr, 3e-6 * math.sqrt(9 * Ci))
-    assert torch.equal(amax, amax2) and torch.equal(ops.from_c16(p16), p32.to(torch.bfloat16))
+    assert torch.equal(amax16, amax2) and torch.equal(ops.from_c16(p16), p32.to(torch.bfloat16))
     assert bool(((p32 == 0) == (amax == 4)).all())
     # the same result as the implicit-GEMM kernel up to fp32 summation order; identical arg-max wherever the winner is clear
     if Ci % 64 == 0:
@@ -452,30 +455,27 @@ def test_pconv_fwd_dgrad_wgrad(B, H, W, Ci, Co):
         assert float((q32 - p32).abs().max()) <= 1e-5 * max(1.0, float(q32.abs().max()))
         assert float((amax_ig != amax).float().mean()) < 1e-3
 
-    # pre-pool gradient, materialised: dy_pad[b, y+2, x+2, c] = dP[b, y//2, x//2, c] iff argmax == (y%2)*2 + x%2
+    # the pre-pool gradient the backward kernels route for themselves: dY[b, y, x, c] = dP[b, y//2, x//2, c] iff
+    # argmax == (y%2)*2 + x%2 -- built here with the KERNEL's arg-max (a float64 near-tie may pick another pixel of a window)
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
-    Hp, Wp = yr.shape[2], yr.shape[3]
-    dyp = ops.pconv_expand_dy(dyd, amax, H, W)
-    torch.cuda.synchronize()
-    Hd, Wd = ops.pconv_dy_dims(H, W)
-    assert Hd >= H + 2 and Wd >= W + 2 and tuple(dyp.shape) == (B, Co // 16, Hd, Wd, 16)
-    ref = torch.zeros(B, Hd, Wd, Co, dtype=torch.bfloat16, device=DEV)
+    dpc = ops.to_c16(dyd)
+    ref = torch.zeros(B, H - 2, W - 2, Co, dtype=torch.bfloat16, device=DEV)
     for j in range(4):
         sel = torch.where(amax == j, dyd, torch.zeros_like(dyd))
-        ref[:, 2 + (j >> 1):2 + 2 * Hp:2, 2 + (j & 1):2 + 2 * Wp:2, :] = sel
-    assert torch.equal(ops.from_c16(dyp), ref)
-    # reference gradients with the KERNEL's arg-max (a float64 near-tie may pick another pixel of a window)
-    dyfull = ref[:, 2:H, 2:W, :].float().permute(0, 3, 1, 2).double().cpu()
+        ref[:, (j >> 1):2 * Hp:2, (j & 1):2 * Wp:2, :] = sel
+    dyfull = ref.float().permute(0, 3, 1, 2).double().cpu()
     if Ci % 64 == 0:
-        dx32 = ops.pconv_dgrad(dyp, wd, xd.shape, out_dtype=torch.float32)
-        dx16 = ops.pconv_dgrad(dyp, wd, xd.shape)
+        dx32 = ops.pconv_dgrad(dpc, amax16, wd, xd.shape, out_dtype=torch.float32)
+        dx16 = ops.pconv_dgrad(dpc, amax16, wd, xd.shape)
+        dxc = ops.pconv_dgrad(dpc, amax16, wd, xd.shape, out_c16=True)
         torch.cuda.synchronize()
         dx_ref = torch.nn.grad.conv2d_input(xr.shape, wr.detach(), dyfull)
         check(f"pconv dgrad fp32-out {tag}", dx32.permute(0, 3, 1, 2), dx_ref, 5e-6 * math.sqrt(9 * Co))
         assert torch.equal(dx16, dx32.to(torch.bfloat16))
+        assert tuple(dxc.shape) == (B, Ci // 16, H, W, 16) and torch.equal(ops.from_c16(dxc), dx16)
     if ops.pconv_wgrad_supported(H, W, Ci, Co):
         dw, db = torch.empty(Co, Ci, 3, 3, device=DEV), torch.empty(Co, device=DEV)
-        ops.pconv_wgrad(xc, dyp, dyd, amax, dw, db)
+        ops.pconv_wgrad(xc, dpc, amax16, dw, db)
         torch.cuda.synchronize()
         dw_ref = torch.nn.grad.conv2d_weight(xr.detach(), wr.shape, dyfull)
         check(f"pconv wgrad {tag}", dw, dw_ref, 2e-5)

@@ -66,22 +66,20 @@ def main():
         xc = ops.to_c16(x)
         pooled, am = ops.pconv_fwd(xc, wf, b, Co, out_dtype=od, tag=l)
         run(f"conv{l} pconv fwd", flops, lambda: ops.pconv_fwd(xc, wf, b, Co, out_dtype=od, tag=l))
-        dp = torch.randn(am.shape, device=dev).to(torch.bfloat16)
-        dyp = ops.pconv_expand_dy(dp, am, Hin, Hin)
-        gb = (dp.numel() * 3 + dyp.numel() * 2) / 1e9
-        ms = timeit(lambda: ops.pconv_expand_dy(dp, am, Hin, Hin), args.iters)
-        print(f"conv{l} expand_dy               {ms:9.3f} ms  {gb / ms * 1e3:8.1f} GB/s", flush=True)
-        run(f"conv{l} pconv dgrad", flops * (Hin * Hin) / (Ho * Ho), lambda: ops.pconv_dgrad(dyp, wd, x.shape, tag=l))
+        dp = torch.randn(am.shape, device=dev).to(torch.bfloat16)          # C16, like the arg-max bytes
+        run(f"conv{l} pconv dgrad", flops * (Hin * Hin) / (Ho * Ho),
+            lambda: ops.pconv_dgrad(dp, am, wd, x.shape, out_c16=l > 1, tag=l))
         if ops.pconv_wgrad_supported(Hin, Hin, Ci, Co):
             dw, db = torch.empty_like(w), torch.empty_like(b)
-            run(f"conv{l} pconv wgrad", flops, lambda: ops.pconv_wgrad(xc, dyp, dp, am, dw, db, tag=l))
+            run(f"conv{l} pconv wgrad", flops, lambda: ops.pconv_wgrad(xc, dp, am, dw, db, tag=l))
         if not args.skip_old:
             wfT, wdT = ops.conv_pack_weights_bf16(w, Ci)
             run(f"conv{l} implicit-GEMM fwd", flops, lambda: ops.conv_fwd_bf16(x, wfT, b, 1, out_dtype=od, tag=l))
-            run(f"conv{l} implicit-GEMM dgrad", flops, lambda: ops.conv_dgrad_bf16(dp, am, wdT, x.shape, 1, tag=l))
+            dpn, amn = ops.from_c16(dp), ops.from_c16(am)
+            run(f"conv{l} implicit-GEMM dgrad", flops, lambda: ops.conv_dgrad_bf16(dpn, amn, wdT, x.shape, 1, tag=l))
             dw, db = torch.empty_like(w), torch.empty_like(b)
-            run(f"conv{l} implicit-GEMM wgrad", flops, lambda: ops.conv_wgrad_bf16(x, dp, am, dw, db, 1, tag=l))
-        del x, xc, dyp, dp, pooled, am
+            run(f"conv{l} implicit-GEMM wgrad", flops, lambda: ops.conv_wgrad_bf16(x, dpn, amn, dw, db, 1, tag=l))
+        del x, xc, dp, pooled, am
         torch.cuda.empty_cache()
 
 

@@ -38,14 +38,13 @@ def fwd(L, l):
 
 def wgrad(L, l):
     if bf:
-        return ops.pconv_wgrad(L["xc"], L["dyp"], L["dp"], L["am"], L["dw"], L["db"], tag=l + 1)
+        return ops.pconv_wgrad(L["xc"], L["dp"], L["am"], L["dw"], L["db"], tag=l + 1)
     return ops.conv_wgrad(L["x"], L["dp"], L["am"], L["dw"], L["db"], 1, tag=l + 1)
 
 
 def dgrad(L, l):
     if bf:
-        L["dyp"] = ops.pconv_expand_dy(L["dp"], L["am"], L["x"].shape[1], L["x"].shape[2])
-        return ops.pconv_dgrad(L["dyp"], L["wd"], L["x"].shape, tag=l + 1)
+        return ops.pconv_dgrad(L["dp"], L["am"], L["wd"], L["x"].shape, out_c16=l > 0, tag=l + 1)
     return ops.conv_dgrad(L["dp"], L["am"], L["wd"], L["x"].shape, 1, tag=l + 1, out=L["dx"])
 
 

@@ -27,8 +27,6 @@ def per_kernel(d, counter):
                 key = "conv_fwd" if m.group(1) in "01" else "conv_dgrad"
             elif short.startswith("pconv_wgrad_kernel"):
                 key = "conv_wgrad"
-            elif short.startswith("pconv_expand_dy_kernel"):
-                key = "expand_dy"
             if key:
                 out.setdefault(key, []).append(float(v))
                 NAMES.setdefault(key, []).append(short)

@@ -282,6 +282,185 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_bf16_kernel(const void* __re
   }
 }
 
+// ------------------------------------------------------------------ forward on bf16 MFMA, C16 output, persistent
+// The kernel above is a one-shot workgroup: stage the patch (a chain of HBM loads, nothing else to do), barrier, compute --
+// with the fp32 patch (56 KB at W = 448) only two workgroups fit a CU, and half of a workgroup's 40 us life was the staging
+// (2.2 ms per launch at 512 x 448 x 448 against 1.1 ms of HBM time).  Here a PERSISTENT workgroup walks (image, block of
+// C0_FR pooled rows) items; the next item's image rows are loaded into REGISTERS before the current item's tiles are
+// computed and go to LDS after them, so HBM latency runs under the MFMA / epilogue work; the patch is held as bf16 (the
+// rounding the MFMA operand gets anyway, applied once per pixel instead of once per tap): 28 KB; eight waves per workgroup
+// (half the prefetch registers per thread), two workgroups per CU.
+// XH: the image is __half (the dataset's features) / float.
+// NWV waves per workgroup: 8 (two workgroups per CU) for __half images, 16 (one per CU) for float ones -- 16 waves per CU either
+// way, and the prefetch stays at 16 VGPRs per thread (the budget at 4 waves per SIMD is 128).
+template <int CI, int TN, bool XH>
+__global__ __launch_bounds__(XH ? 512 : 1024, 4) void conv0_fwd_c16_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, uint16_t* pooled16, uint8_t* amax,
+                                                            int B, int H, int W, int Hp, int Wp, int RS, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) char c0lds[];
+  uint16_t* const patch = reinterpret_cast<uint16_t*>(c0lds);          // [CI][C0_PR][RS] bf16, RS % 64 == 16
+  constexpr int K = 9 * CI, Co = 32 * TN;
+  static_assert(K <= 32, "two 16-deep k-steps cover at most 32 taps");
+  static_assert(CI * C0_PR <= 32, "the staged rows are dealt over 32 wave slots");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int plane = C0_PR * RS;
+  const int W4 = W >> 2;
+  constexpr int NWV = XH ? 8 : 16;
+  constexpr int NQ = 2 * (32 / NWV);                     // pieces per thread: 32 / NWV rows x 2 column pieces (host check: W <= 512)
+  typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+  h16x4 rh[XH ? NQ : 1];
+  float4 rf[XH ? 1 : NQ];
+
+  // weights as bf16 B fragments (element e of k-step ks: tap k = 16 ks + 8 h + e) parked in LDS, one 16-byte read per
+  // fragment and tile (in registers they were 8 TN VGPRs the prefetch needs); tap offsets as per-lane constants, two 16-bit
+  // offsets per register
+  char* const wl = c0lds + CI * C0_PR * RS * 2 + NWV * (8 * Co * 3);     // [2 ks][TN][64 lanes][16 bytes]
+  uint32_t koff2[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    float wv[TN][8];
+    int ko[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * ks + 8 * h + e;
+      const bool kok = k < K;
+      const int kk = kok ? k : 0;
+      const int c = kk / 9, t = kk - 9 * c, ky = t / 3, kx = t - 3 * ky;
+      ko[e] = c * plane + ky * RS + kx;                  // taps >= K read tap 0 (finite) against a zero weight
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wv[j][e] = kok ? w[(int64_t)(32 * j + l31) * K + kk] : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) koff2[ks][m] = (uint32_t)ko[2 * m] | ((uint32_t)ko[2 * m + 1] << 16);
+    if (wave == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        *reinterpret_cast<uint4*>(wl + ((ks * TN + j) * 64 + lane) * 16) =
+            make_uint4(pack_bf16x2(wv[j][0], wv[j][1]), pack_bf16x2(wv[j][2], wv[j][3]), pack_bf16x2(wv[j][4], wv[j][5]),
+                       pack_bf16x2(wv[j][6], wv[j][7]));
+    }
+  }
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[j] = bias[32 * j + l31];
+
+  // wave wv stages rows wv, wv + NWV, .. of the CI * C0_PR patch rows; a lane takes the 4-pixel pieces lane and lane + 64 of a row
+  // (W <= 512): row bases are wave-uniform, the prefetch registers hold data only
+  auto load_item = [&](int item) {
+    const int b = item / nblk, py0 = C0_FR * (item - b * nblk);
+    const int nrows = 2 * min(C0_FR, Hp - py0) + 2;
+    const int64_t img = ((int64_t)b * CI * H + 2 * py0) * W;
+#pragma unroll
+    for (int i = 0; i < NQ / 2; ++i) {
+      const int r = wave + NWV * i, c = r / C0_PR, rr = r - c * C0_PR;
+      const int64_t e = img + ((int64_t)c * H + rr) * W;
+      const bool rok = r < CI * C0_PR && rr < nrows;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c4 = lane + 64 * u;
+        const bool ok = rok && c4 < W4;
+        if (XH) rh[2 * i + u] = ok ? *reinterpret_cast<const h16x4*>(static_cast<const uint16_t*>(x) + e + 4 * c4) : h16x4{0, 0, 0, 0};
+        else rf[2 * i + u] = ok ? *reinterpret_cast<const float4*>(static_cast<const float*>(x) + e + 4 * c4) : f4zero();
+      }
+    }
+  };
+  auto store_item = [&]() {
+#pragma unroll
+    for (int i = 0; i < NQ / 2; ++i) {
+      const int r = wave + NWV * i;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c4 = lane + 64 * u;
+        if (r < CI * C0_PR && c4 < W4) {
+          float4 v;
+          if (XH) v = make_float4((float)rh[2 * i + u][0], (float)rh[2 * i + u][1], (float)rh[2 * i + u][2], (float)rh[2 * i + u][3]);
+          else v = rf[2 * i + u];
+          *reinterpret_cast<uint2*>(patch + r * RS + 4 * c4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
+      }
+    }
+  };
+
+  const int nitems = B * nblk;
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  load_item(item);
+  char* const scr = c0lds + CI * C0_PR * RS * 2 + wave * (8 * Co * 3);
+  char* const sam = scr + 8 * Co * 2;
+  const int plane16 = Hp * Wp * 16;                     // elements of one 16-channel block of one image
+  for (; item < nitems; item += gridDim.x) {
+    __syncthreads();                                    // the previous item's tiles are done with the patch
+    store_item();
+    __syncthreads();
+    const int nxt = item + gridDim.x;
+    if (nxt < nitems) load_item(nxt);                   // in flight under this item's tiles
+    const int b = item / nblk, py0 = C0_FR * (item - b * nblk);
+    const int nwr = min(C0_FR, Hp - py0);
+    const int nwin = nwr * Wp, ntiles = (nwin + 7) / 8;
+    const int64_t o0 = (int64_t)(b * Hp + py0) * Wp * Co;
+    const int64_t o16 = ((int64_t)b * (Co / 16) * Hp + py0) * Wp * 16;
+    const __amdgpu_buffer_rsrc_t rp = buf_rsrc(pooled16 + o16), ra = buf_rsrc(amax + o0);
+    for (int t = wave; t < ntiles; t += NWV) {
+      int wdx = 8 * t + (l31 >> 2);
+      if (wdx >= nwin) wdx = 0;
+      const int wr = (wdx >= Wp ? 1 : 0) + (wdx >= 2 * Wp ? 1 : 0) + (wdx >= 3 * Wp ? 1 : 0);
+      const int px = wdx - __mul24(wr, Wp), j4 = l31 & 3;
+      const uint16_t* ap = patch + __mul24(2 * wr + (j4 >> 1), RS) + 2 * px + (j4 & 1);
+      f32x16 acc[TN];
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint32_t pkv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          pkv[m] = (uint32_t)ap[koff2[ks][m] & 0xffffu] | ((uint32_t)ap[koff2[ks][m] >> 16] << 16);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(pkv[0], pkv[1], pkv[2], pkv[3]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bf16x8 bwf = *reinterpret_cast<const bf16x8*>(wl + ((ks * TN + j) * 64 + lane) * 16);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bwf, ks == 0 ? zero : acc[j], 0, 0, 0);
+        }
+      }
+      const bool inner = 8 * t + 8 <= nwin;
+      // the tile's 8 windows x Co channels through the wave's LDS scratch -- pooled as [16-channel block][window][16] bf16,
+      // arg-max as [window][Co] bytes -- and out as ONE 16-byte-per-lane store each
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float best = acc[j][4 * g];
+          int a = 0;
+          if (acc[j][4 * g + 1] > best) { best = acc[j][4 * g + 1]; a = 1; }
+          if (acc[j][4 * g + 2] > best) { best = acc[j][4 * g + 2]; a = 2; }
+          if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
+          best += bv[j];
+          const int win = 2 * g + h;
+          *reinterpret_cast<uint16_t*>(scr + (((2 * j + (l31 >> 4)) * 8 + win) * 16 + (l31 & 15)) * 2) = bf16_bits(best > 0.f ? best : 0.f);
+          *reinterpret_cast<uint8_t*>(sam + win * Co + 32 * j + l31) = best > 0.f ? (uint8_t)a : (uint8_t)4;
+        }
+      }
+      asm volatile("" ::: "memory");        // the wave's LDS accesses execute in order; keep the compiler's order as well
+      {
+        const int byte = lane * 16;          // pooled: 2 TN blocks x 8 windows x 32 bytes = 8 * Co * 2 bytes
+        if (byte < 8 * Co * 2) {
+          const int blk = byte >> 8, win = (byte & 255) >> 5, inrun = byte & 31;
+          const float4 v = *reinterpret_cast<const float4*>(scr + byte);
+          const bool ok = inner || 8 * t + win < nwin;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp,
+                                                 ok ? (int)(blk * plane16 * 2 + (8 * t + win) * 32 + inrun) : (int)BUF_OOB, 0, 0);
+        }
+        if (byte < 8 * Co) {                 // arg-max: 8 windows x Co bytes, contiguous in NHWC
+          const int win = byte / Co;
+          const float4 v = *reinterpret_cast<const float4*>(sam + byte);
+          const bool ok = inner || 8 * t + win < nwin;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ra, ok ? (int)(8 * t * Co + byte) : (int)BUF_OOB, 0, 0);
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad
 // persistent grid; 256 threads; LDS = CI*PLANE (x patch, 4 rows) + Wp*Co (dP row) floats + Wp*Co bytes (arg-max row)
 template <int CI, int TN>
@@ -375,11 +554,15 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const void* __restrict
 //     arg-max == 2 hs + parity; the 4 windows serve both conv rows hs = 0, 1 of the pooled row.
 // Persistent workgroups walk pooled rows; each wave keeps 32 x Co partial sums in accumulators for its whole life and
 // the four waves combine through LDS at the end: ONE slab per workgroup (deterministic, no atomics).
-template <int CI, int TN>
-__global__ __launch_bounds__(256) void conv0_wgrad_bf16_kernel(const void* __restrict__ x, int xh, const uint16_t* __restrict__ dp,
-                                                               const uint8_t* __restrict__ am, float* slab,
-                                                               float* bias_slab, int B, int H, int W, int Hp, int Wp,
-                                                               int RSTR, int NG) {
+// The NEXT row's operands (image rows, pooled gradient, arg-max bytes) are loaded into registers before the current row is
+// computed and go to LDS after it: HBM latency runs under the MFMA / routing work instead of in front of it (the one-shot
+// form -- load, barrier, compute, barrier -- spent two thirds of a row's 21 us waiting at 2 workgroups per CU).
+// XH: the image is __half / float.  W <= 512 (one 8-pixel chunk per lane and image row), Wp * Co <= 16384.
+template <int CI, int TN, bool XH>
+__global__ __launch_bounds__(256, 2) void conv0_wgrad_bf16_kernel(const void* __restrict__ x, const uint16_t* __restrict__ dp,
+                                                                  const uint8_t* __restrict__ am, float* slab,
+                                                                  float* bias_slab, int B, int H, int W, int Hp, int Wp,
+                                                                  int RSTR, int NG) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int K = 9 * CI, Co = 32 * TN;
   static_assert(K <= 32, "the taps are the 32 rows of one MFMA A operand");
@@ -401,37 +584,75 @@ __global__ __launch_bounds__(256) void conv0_wgrad_bf16_kernel(const void* __res
   }
   const int rows_total = B * Hp;
   const int rowv = Wp * Co;
-  for (int row = blockIdx.x; row < rows_total; row += gridDim.x) {
+  // prefetch registers: image = (channel cc: round, image row: wave, 8-pixel chunk: lane), 12 pixels each (8 + the 4 the
+  // shifted copies need); pooled gradient / arg-max = 16-byte / 8-byte pieces tid + 256 i
+  constexpr int DR = 8;
+  typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+  h16x4 xh_[XH ? CI : 1][3];
+  float4 xf_[XH ? 1 : CI][3];
+  uint4 dr_[DR];
+  uint2 ar_[DR];
+  const int npieces = WpP * Co / 8;
+  auto load_row = [&](int row) {
     const int b = row / Hp, py = row - b * Hp;
-    __syncthreads();   // previous row fully consumed
-    // image rows 2py .. 2py+3 of every channel -> three shifted bf16 copies
-    for (int e = tid; e < CI * 4 * 2 * NG; e += 256) {
-      const int i = e % (2 * NG);                       // chunk of 8 positions
-      const int r = (e / (2 * NG)) & 3;
-      const int cc = e / (2 * NG) / 4;
-      const int64_t src = ((int64_t)(b * CI + cc) * H + 2 * py + r) * W + 8 * i;
-      float v[12];
+#pragma unroll
+    for (int cc = 0; cc < CI; ++cc) {
+      const int64_t src = ((int64_t)(b * CI + cc) * H + 2 * py + wave) * W + 8 * lane;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const float4 f = 8 * i + 4 * q < W ? c0_load4(x, src + 4 * q, xh) : f4zero();   // W % 4 == 0
-        v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
-      }
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const uint4 pk = make_uint4(pack_bf16x2(v[s], v[s + 1]), pack_bf16x2(v[s + 2], v[s + 3]),
-                                    pack_bf16x2(v[s + 4], v[s + 5]), pack_bf16x2(v[s + 6], v[s + 7]));
-        *reinterpret_cast<uint4*>(P16 + ((s * CI + cc) * 4 + r) * RSTR + 16 * i) = pk;
+        const bool ok = 8 * lane + 4 * q < W;                       // W % 4 == 0
+        if (XH) xh_[cc][q] = ok ? *reinterpret_cast<const h16x4*>(static_cast<const uint16_t*>(x) + src + 4 * q) : h16x4{0, 0, 0, 0};
+        else xf_[cc][q] = ok ? *reinterpret_cast<const float4*>(static_cast<const float*>(x) + src + 4 * q) : f4zero();
       }
     }
-    // pooled gradient row and arg-max row (padding windows: gradient 0, arg-max 4)
     const uint16_t* dprow = dp + (int64_t)row * rowv;
     const uint8_t* amrow = am + (int64_t)row * rowv;
-    for (int e = tid; e < WpP * Co / 8; e += 256) {
-      const bool in = 8 * e < rowv;                      // Co % 8 == 0: a chunk never straddles the row end
-      reinterpret_cast<uint4*>(dps)[e] = in ? reinterpret_cast<const uint4*>(dprow)[e] : make_uint4(0u, 0u, 0u, 0u);
-      reinterpret_cast<uint2*>(ams)[e] = in ? reinterpret_cast<const uint2*>(amrow)[e] : make_uint2(0x04040404u, 0x04040404u);
+#pragma unroll
+    for (int i = 0; i < DR; ++i) {
+      const int e = tid + 256 * i;
+      const bool in = 8 * e < rowv;                      // Co % 8 == 0: a piece never straddles the row end
+      dr_[i] = in ? reinterpret_cast<const uint4*>(dprow)[e] : make_uint4(0u, 0u, 0u, 0u);
+      ar_[i] = in ? reinterpret_cast<const uint2*>(amrow)[e] : make_uint2(0x04040404u, 0x04040404u);   // padding windows: dead
     }
+  };
+  auto store_row = [&]() {
+    if (lane < 2 * NG) {
+#pragma unroll
+      for (int cc = 0; cc < CI; ++cc) {
+        float v[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          if (XH) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[4 * q + u] = (float)xh_[cc][q][u];
+          } else {
+            v[4 * q] = xf_[cc][q].x; v[4 * q + 1] = xf_[cc][q].y; v[4 * q + 2] = xf_[cc][q].z; v[4 * q + 3] = xf_[cc][q].w;
+          }
+        }
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft) {
+          const uint4 pk = make_uint4(pack_bf16x2(v[sft], v[sft + 1]), pack_bf16x2(v[sft + 2], v[sft + 3]),
+                                      pack_bf16x2(v[sft + 4], v[sft + 5]), pack_bf16x2(v[sft + 6], v[sft + 7]));
+          *reinterpret_cast<uint4*>(P16 + ((sft * CI + cc) * 4 + wave) * RSTR + 16 * lane) = pk;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DR; ++i) {
+      const int e = tid + 256 * i;
+      if (e < npieces) {
+        reinterpret_cast<uint4*>(dps)[e] = dr_[i];
+        reinterpret_cast<uint2*>(ams)[e] = ar_[i];
+      }
+    }
+  };
+  int row = blockIdx.x;
+  if (row < rows_total) load_row(row);
+  for (; row < rows_total; row += gridDim.x) {
+    __syncthreads();   // previous row fully consumed
+    store_row();
     __syncthreads();
+    if (row + (int)gridDim.x < rows_total) load_row(row + gridDim.x);     // in flight under this row's MFMAs
     for (int g = wave; g < NG; g += 4) {
       uint32_t d[TN][4], a8[TN][4];
 #pragma unroll
@@ -556,12 +777,29 @@ int vqa_conv0_relu_pool_fwd(const void* x_nchw, int x_is_fp16, const float* w, c
     C0_DISPATCH(Ci, Co / 32, {
       if constexpr (kCI <= 3) {
         if (pooled_is_bf16 == 4) {
-          auto kern = conv0_fwd_bf16_kernel<kCI, kTN, true>;
-          const size_t lds16 = lds + (size_t)4 * 8 * Co * 3;       // + the four waves' epilogue scratch
-          int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds16, "attr(conv0_fwd_bf16 C16)");
-          if (rc0) return rc0;
-          hipLaunchKernelGGL(kern, grid, dim3(256), lds16, (hipStream_t)stream, x_nchw, xh, w, bias, static_cast<uint16_t*>(pooled),
-                             argmax, H, W, Hp, Wp, RS);
+          // persistent, register-prefetched, bf16 patch (row stride = 16 mod 64 elements: the two image rows of a gather sit
+          // 8 banks apart)
+          int RS16 = W + 2;
+          while (RS16 % 64 != 16) ++RS16;
+          const int nwv = xh ? 8 : 16;
+          const size_t lds16 = (size_t)kCI * C0_PR * RS16 * 2 + (size_t)nwv * 8 * Co * 3 + (size_t)2 * kTN * 1024;
+          VQA_REQUIRE(W <= 512, "vqa_conv0_relu_pool_fwd: image too wide for the C16 kernel (W=%d)", W);
+          const int nblk = (Hp + C0_FR - 1) / C0_FR;
+          int blocks = 256 * (xh ? 2 : 1);
+          if (blocks > B * nblk) blocks = B * nblk;
+          if (xh) {
+            auto kern = conv0_fwd_c16_kernel<kCI, kTN, true>;
+            int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds16, "attr(conv0_fwd_c16)");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds16, (hipStream_t)stream, x_nchw, w, bias, static_cast<uint16_t*>(pooled),
+                               argmax, B, H, W, Hp, Wp, RS16, nblk);
+          } else {
+            auto kern = conv0_fwd_c16_kernel<kCI, kTN, false>;
+            int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds16, "attr(conv0_fwd_c16)");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds16, (hipStream_t)stream, x_nchw, w, bias, static_cast<uint16_t*>(pooled),
+                               argmax, B, H, W, Hp, Wp, RS16, nblk);
+          }
         } else {
           auto kern = conv0_fwd_bf16_kernel<kCI, kTN, false>;
           int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd_bf16)");
@@ -629,9 +867,9 @@ int vqa_conv0_wgrad_bf16(const void* x_nchw, int x_is_fp16, const void* dpooled_
   size_t lds = (size_t)3 * Ci * 4 * RSTR + (size_t)8 * NG * Co * 3;
   if (lds < (size_t)(4 * 32 + 4) * Co * 4) lds = (size_t)(4 * 32 + 4) * Co * 4;   // the end-of-kernel combine area
   lds = (lds + 15) & ~(size_t)15;
-  VQA_REQUIRE(lds <= 160 * 1024, "vqa_conv0_wgrad_bf16: image too wide for LDS (W=%d)", W);
+  VQA_REQUIRE(lds <= 160 * 1024 && W <= 512 && 8 * NG * Co <= 16384, "vqa_conv0_wgrad_bf16: image too wide (W=%d)", W);
   int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 3) per_cu = 3;
+  if (per_cu > 2) per_cu = 2;                          // 2 waves per SIMD: the prefetch registers
   int blocks = 256 * per_cu;
   if (blocks > B * Hp) blocks = B * Hp;
   float* slab = workspace;
@@ -639,11 +877,19 @@ int vqa_conv0_wgrad_bf16(const void* x_nchw, int x_is_fp16, const void* dpooled_
   hipStream_t s = (hipStream_t)stream;
   C0_DISPATCH(Ci, Co / 32, {
     if constexpr (kCI <= 3) {
-      auto kern = conv0_wgrad_bf16_kernel<kCI, kTN>;
-      int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad_bf16)");
-      if (rc0) return rc0;
-      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, x_is_fp16 ? 1 : 0, static_cast<const uint16_t*>(dpooled_bf16),
-                         argmax, slab, bias_slab, B, H, W, Hp, Wp, RSTR, NG);
+      if (x_is_fp16) {
+        auto kern = conv0_wgrad_bf16_kernel<kCI, kTN, true>;
+        int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad_bf16)");
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, static_cast<const uint16_t*>(dpooled_bf16), argmax, slab,
+                           bias_slab, B, H, W, Hp, Wp, RSTR, NG);
+      } else {
+        auto kern = conv0_wgrad_bf16_kernel<kCI, kTN, false>;
+        int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad_bf16)");
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, static_cast<const uint16_t*>(dpooled_bf16), argmax, slab,
+                           bias_slab, B, H, W, Hp, Wp, RSTR, NG);
+      }
     }
   });
   int rc = check_hip(hipGetLastError(), "conv0_wgrad_bf16 launch");

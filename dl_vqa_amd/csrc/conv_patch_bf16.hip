@@ -720,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
       // older is in flight), then the loads for the stage after it.  The two waves of a SIMD do it at different k-steps, so the
       // VALU / ds_write burst of one runs under the other's MFMAs -- the half that issued this stage's DMA pieces later (hipcc's
       // wait for the two loads is a vmcnt(0): it would wait for pieces issued just before, too).
-      if (s == (half == (buf ^ (k & 0)) ? 5 : 2)) {
+      if (s == (half == buf ? 5 : 2)) {
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < my_tiles) rt_route(buf ^ 1);
         rt_load();

@@ -371,7 +371,7 @@ def test_conv0_bf16_mfma_forward():
     """First block on bf16 MFMA (image and weights rounded to bf16, fp32 accumulate) against float64 on rounded inputs,
     incl. a 448-wide image (> 64 KB of LDS)."""
     ops = _ops()
-    for (B, H, W, Co) in ((2, 30, 32, 64), (1, 22, 448, 64), (3, 17, 20, 32)):
+    for (B, H, W, Co) in ((2, 30, 32, 64), (1, 22, 448, 64), (3, 17, 20, 32), (7, 50, 132, 64), (40, 26, 24, 64)):
         g = torch.Generator().manual_seed(H + W)
         x = torch.randn(B, 3, H, W, generator=g)
         w = torch.randn(Co, 3, 3, 3, generator=g) * 0.2
@@ -381,13 +381,21 @@ def test_conv0_bf16_mfma_forward():
         torch.cuda.synchronize()
         check(f"conv0 bf16-MFMA fwd {B,H,W,Co}", p16.float().permute(0, 3, 1, 2), ref, 2 ** -8)
         assert bool(((p16 == 0) == (am == 4)).all())
+        # the persistent channel-blocked form (what the patch convolutions read), float and __half images (the dataset's
+        # features, widened exactly): the same bits
+        xh = x.half()
+        ph, amh = ops.conv0_fwd(xh.float().to(DEV), w.to(DEV), b.to(DEV), out_dtype=torch.bfloat16, bf16_mfma=True)
+        for xin in (xh.float(), xh):
+            pc, amc = ops.conv0_fwd(xin.to(DEV), w.to(DEV), b.to(DEV), out_dtype=torch.bfloat16, bf16_mfma=True, out_c16=True)
+            torch.cuda.synchronize()
+            assert torch.equal(ops.from_c16(pc), ph) and torch.equal(amc, amh), (B, H, W, Co, xin.dtype)
 
 
 def test_conv0_bf16_mfma_wgrad():
     """First block's weight / bias gradient on bf16 MFMA (image rounded to bf16, bf16 pooled gradient) against float64
     autograd on the rounded operands; odd sizes (pixel groups with padding), a 448-wide image, several images."""
     ops = _ops()
-    for (B, H, W, Co) in ((2, 30, 32, 64), (1, 14, 448, 64), (3, 17, 20, 32), (5, 40, 44, 64)):
+    for (B, H, W, Co) in ((2, 30, 32, 64), (1, 14, 448, 64), (3, 17, 20, 32), (5, 40, 44, 64), (300, 12, 16, 64)):
         g = torch.Generator().manual_seed(H * 3 + W)
         x = torch.randn(B, 3, H, W, generator=g)
         w = torch.randn(Co, 3, 3, 3, generator=g) * 0.2
@@ -402,6 +410,14 @@ def test_conv0_bf16_mfma_wgrad():
         torch.cuda.synchronize()
         check(f"conv0 bf16-MFMA wgrad {B,H,W,Co}", dw, wr.grad, 3e-5)
         check(f"conv0 bf16-MFMA bias grad {B,H,W,Co}", db, br.grad, 3e-5)
+        # __half image: the same bits as its widened copy
+        xh = x.half()
+        dyd = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+        dw1, db1, dw2, db2 = (torch.empty_like(dw), torch.empty_like(db), torch.empty_like(dw), torch.empty_like(db))
+        ops.conv0_wgrad_bf16(xh.float().to(DEV), dyd, am, dw1, db1)
+        ops.conv0_wgrad_bf16(xh.to(DEV), dyd, am, dw2, db2)
+        torch.cuda.synchronize()
+        assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
 
 
 def test_bf16_path_rejects_unsupported_configs():

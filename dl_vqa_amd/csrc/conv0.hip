@@ -654,26 +654,29 @@ __global__ __launch_bounds__(256, 2) void conv0_wgrad_bf16_kernel(const void* __
     __syncthreads();
     if (row + (int)gridDim.x < rows_total) load_row(row + gridDim.x);     // in flight under this row's MFMAs
     for (int g = wave; g < NG; g += 4) {
-      uint32_t d[TN][4], a8[TN][4];
+      // routing without branches or selects: a window's gradient, zeroed when the window is dead (code 4), shifted to the
+      // 16-bit field of its arg-max pixel in a 64-bit word [pixel 0 | 1 | 2 | 3] -- the low half is the B-operand pair of
+      // conv row hs = 0, the high half that of hs = 1 (the compare-and-select form compiled to ~60 skip branches per group)
+      uint32_t wlo[TN][4], whi[TN][4];
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int o = (8 * g + 4 * h + m) * Co + 32 * j + l31;
-          d[j][m] = dps[o];
-          a8[j][m] = ams[o];
-          bsum[j] += a8[j][m] != 4u ? __uint_as_float(d[j][m] << 16) : 0.f;
+          const uint32_t code = ams[o];
+          const uint32_t dz = (uint32_t)dps[o] & ((code >> 2) - 1u);          // codes 0..3 keep, 4 clears
+          bsum[j] += __uint_as_float(dz << 16);
+          const uint64_t f = (uint64_t)dz << ((code & 3u) * 16u);
+          wlo[j][m] = (uint32_t)f;
+          whi[j][m] = (uint32_t)(f >> 32);
         }
 #pragma unroll
       for (int hs = 0; hs < 2; ++hs) {
         const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + hs * RSTR + 32 * g));
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          uint32_t w[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            w[m] = a8[j][m] == (uint32_t)(2 * hs) ? d[j][m] : (a8[j][m] == (uint32_t)(2 * hs + 1) ? d[j][m] << 16 : 0u);
-          const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+          const bf16x8 bf = __builtin_bit_cast(bf16x8, hs ? make_uint4(whi[j][0], whi[j][1], whi[j][2], whi[j][3])
+                                                          : make_uint4(wlo[j][0], wlo[j][1], wlo[j][2], wlo[j][3]));
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
         }
       }

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "vqa_dropout_add": (i32, [f32p, f32p, i64, f32, u64, vp]),
     "vqa_l2norm_fwd": (i32, [f32p, f32p, f32p, i64, i32, f32, u64, vp, i32, f32, u64, vp]),
     "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, vp, i32, i64, i32, i32, f32, u64, vp]),
+    "vqa_l2norm_bwd_joined": (i32, [f32p, i64, f32p, i32, f32p, f32, u64, f32p, f32p, vp, i32, i64, i32, i32, f32, u64, vp]),
     "vqa_embed_tanh_fwd": (i32, [i64p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp, vp]),
     "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
     "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),

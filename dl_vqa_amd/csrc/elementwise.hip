@@ -111,10 +111,15 @@ __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, i
 
 // OB 1 / 2: the gradient is stored as bf16 (bf16 path: it is the pooled gradient of the last conv block, staged as bf16 anyway);
 // 2: channel-blocked [image][C/16][position][16] -- what the routed patches of the patch convolutions read (a lane's 4
-// channels are 8 bytes of one block; the four rows of a workgroup are consecutive positions = 128 contiguous bytes per block)
-template <int OB>
+// channels are 8 bytes of one block; the four rows of a workgroup are consecutive positions = 128 contiguous bytes per block).
+// G > 0: the incoming gradient is JOINED here instead of being read -- d loss / d vn = the weighted-sum branch
+// sum_g probs[b][g][p] * dout[b][g][:] (what att_apply_bwd wrote as dvn) + dropout-mask * dv_in (what dropout_add added):
+// two full passes over a [B*P][C] fp32 tensor less per step.  Same operations in the same order as the separate kernels.
+template <int OB, int G>
 __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float* norm, void* dpooled_,
-                                  int64_t rows, int C, float p, float inv_keep, uint64_t seed, int positions) {
+                                  int64_t rows, int C, float p, float inv_keep, uint64_t seed, int positions,
+                                  const float* dout, int64_t dout_ld, const float* probs, const float* dv_in, float p_v,
+                                  float inv_keep_v, uint64_t seed_v) {
   float* const dpooled = static_cast<float*>(dpooled_);
   uint16_t* const dpooled16 = static_cast<uint16_t*>(dpooled_);
   const int lane = threadIdx.x & 63;
@@ -124,9 +129,31 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float4* g = reinterpret_cast<const float4*>(dvn + r * C);
     const float4* v = reinterpret_cast<const float4*>(vn + r * C);
+    const int64_t img = G > 0 || OB == 2 ? r / positions : 0;
+    const int64_t pos = r - img * positions;
+    float pr[G > 0 ? G : 1];
+    if (G > 0) {
+#pragma unroll
+      for (int q = 0; q < G; ++q) pr[q] = probs[(img * G + q) * positions + pos];
+    }
+    auto grad = [&](int c) -> float4 {
+      if (G == 0) return g[c];
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < (G > 0 ? G : 1); ++q) {
+        const float4 go = reinterpret_cast<const float4*>(dout + img * dout_ld + (int64_t)q * C)[c];
+        o.x += pr[q] * go.x; o.y += pr[q] * go.y; o.z += pr[q] * go.z; o.w += pr[q] * go.w;
+      }
+      float4 x = reinterpret_cast<const float4*>(dv_in + r * C)[c];
+      if (p_v > 0.f) {
+        const float4 ds_ = drop_scale4(seed_v, (uint64_t)r * C + 4 * c, p_v, inv_keep_v);
+        x.x *= ds_.x; x.y *= ds_.y; x.z *= ds_.z; x.w *= ds_.w;
+      }
+      return make_float4(o.x + x.x, o.y + x.y, o.z + x.z, o.w + x.w);
+    };
     float dot = 0.f;
     for (int c = lane; c < nch; c += 64) {
-      const float4 a = g[c], b = v[c];
+      const float4 a = grad(c), b = v[c];
       dot += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     }
     dot = wave_sum(dot);
@@ -136,7 +163,7 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
     float4* dst = reinterpret_cast<float4*>(dpooled + r * C);
     uint2* dst16 = reinterpret_cast<uint2*>(dpooled16 + r * C);
     for (int c = lane; c < nch; c += 64) {
-      const float4 a = g[c], b = v[c];
+      const float4 a = grad(c), b = v[c];
       float4 d = make_float4((a.x - b.x * k) * inv, (a.y - b.y * k) * inv, (a.z - b.z * k) * inv, (a.w - b.w * k) * inv);
       if (p > 0.f) {
         const uint64_t e = (uint64_t)r * C + 4 * c;
@@ -147,7 +174,6 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
         const bf2 lo = {(__bf16)d.x, (__bf16)d.y}, hi = {(__bf16)d.z, (__bf16)d.w};
         const uint2 o = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
         if (OB == 2) {
-          const int64_t img = r / positions, pos = r - img * positions;
           *reinterpret_cast<uint2*>(dpooled16 + ((img * (C >> 4) + (c >> 2)) * positions + pos) * 16 + (c & 3) * 4) = o;
         } else {
           dst16[c] = o;
@@ -577,7 +603,7 @@ __global__ void att_apply_bwd_rows_kernel(const float* dout, int64_t dout_ld, co
         acc[g] += x.x * go.x + x.y * go.y + x.z * go.z + x.w * go.w;
         o.x += pr[g] * go.x; o.y += pr[g] * go.y; o.z += pr[g] * go.z; o.w += pr[g] * go.w;
       }
-      d[c] = o;
+      if (dvn) d[c] = o;       // dvn == null: vqa_l2norm_bwd_joined recomputes this branch where it is consumed
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -796,6 +822,17 @@ using namespace vqa;
 #define STREAM ((hipStream_t)stream)
 #define KEEP(p) ((p) > 0.f ? 1.0f / (1.0f - (p)) : 1.0f)
 
+template <int G>
+static void l2norm_bwd_launch(const float* dvn, const float* vn, const float* norm, void* dpooled, int mode, int64_t rows,
+                              int positions, int C, float p, uint64_t seed, const float* dout, int64_t dout_ld,
+                              const float* probs, const float* dv_in, float p_v, uint64_t seed_v, hipStream_t s) {
+#define L2B(OB)                                                                                                            \
+  hipLaunchKernelGGL((l2norm_bwd_kernel<OB, G>), dim3(grid_for(rows, 4)), dim3(256), 0, s, dvn, vn, norm, dpooled, rows, C, p, \
+                     KEEP(p), seed, positions, dout, dout_ld, probs, dv_in, p_v, KEEP(p_v), seed_v)
+  if (mode == 2) L2B(2); else if (mode == 1) L2B(1); else L2B(0);
+#undef L2B
+}
+
 extern "C" {
 
 int vqa_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, vqa_stream_t stream) {
@@ -831,6 +868,15 @@ int vqa_l2norm_fwd(const float* pooled, float* vn, float* norm, int64_t rows, in
   return check_hip(hipGetLastError(), "l2norm_fwd launch");
 }
 
+#define DISPATCH_G(G, ...)                                         \
+  switch (G) {                                                     \
+    case 1: { constexpr int kG = 1; __VA_ARGS__; } break;          \
+    case 2: { constexpr int kG = 2; __VA_ARGS__; } break;          \
+    case 3: { constexpr int kG = 3; __VA_ARGS__; } break;          \
+    case 4: { constexpr int kG = 4; __VA_ARGS__; } break;          \
+    default: set_error("glimpses=%d unsupported (1..4)", G); return VQA_ERR_INVALID; \
+  }
+
 int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, void* dpooled, int dpooled_mode, int64_t rows,
                    int positions, int C, float p, uint64_t seed, vqa_stream_t stream) {
   set_launch_tag(-1);
@@ -838,16 +884,22 @@ int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, void* d
   VQA_REQUIRE(dvn && vn && norm && dpooled && rows > 0 && C % 4 == 0 && dpooled_mode >= 0 && dpooled_mode <= 2, "vqa_l2norm_bwd: bad args");
   VQA_REQUIRE(dpooled_mode != 2 || (C % 16 == 0 && positions > 0 && rows % positions == 0),
               "vqa_l2norm_bwd: the channel-blocked output needs C %% 16 == 0 and rows = images x positions (C=%d, positions=%d)", C, positions);
-  if (dpooled_mode == 2)
-    hipLaunchKernelGGL(l2norm_bwd_kernel<2>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
-                       C, p, KEEP(p), seed, positions);
-  else if (dpooled_mode == 1)
-    hipLaunchKernelGGL(l2norm_bwd_kernel<1>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
-                       C, p, KEEP(p), seed, positions);
-  else
-    hipLaunchKernelGGL(l2norm_bwd_kernel<0>, dim3(grid_for(rows, 4)), dim3(256), 0, STREAM, dvn, vn, norm, dpooled, rows,
-                       C, p, KEEP(p), seed, positions);
+  l2norm_bwd_launch<0>(dvn, vn, norm, dpooled, dpooled_mode, rows, positions > 0 ? positions : 1, C, p, seed, nullptr, 0, nullptr,
+                       nullptr, 0.f, 0, STREAM);
   return check_hip(hipGetLastError(), "l2norm_bwd launch");
+}
+
+int vqa_l2norm_bwd_joined(const float* dout, int64_t dout_ld, const float* probs, int G, const float* dv_in, float p_v,
+                          uint64_t seed_v, const float* vn, const float* norm, void* dpooled, int dpooled_mode, int64_t rows,
+                          int positions, int C, float p, uint64_t seed, vqa_stream_t stream) {
+  set_launch_tag(-1);
+  ProfScope prof(VQA_K_L2NORM_BWD, (hipStream_t)stream);
+  VQA_REQUIRE(dout && probs && dv_in && vn && norm && dpooled && rows > 0 && C % 4 == 0 && dout_ld % 4 == 0 && dpooled_mode >= 0 &&
+                  dpooled_mode <= 2 && positions > 0 && rows % positions == 0, "vqa_l2norm_bwd_joined: bad args");
+  VQA_REQUIRE(dpooled_mode != 2 || C % 16 == 0, "vqa_l2norm_bwd_joined: the channel-blocked output needs C %% 16 == 0 (C=%d)", C);
+  DISPATCH_G(G, l2norm_bwd_launch<kG>(nullptr, vn, norm, dpooled, dpooled_mode, rows, positions, C, p, seed, dout, dout_ld, probs,
+                                      dv_in, p_v, seed_v, STREAM));
+  return check_hip(hipGetLastError(), "l2norm_bwd_joined launch");
 }
 
 int vqa_embed_tanh_fwd(const int64_t* q, const float* emb, float* x, int B, int T, int E, int V, float p,
@@ -881,15 +933,6 @@ int vqa_lstm_cell_bwd(const float* gates, const float* c_in, const float* c_out,
                      c_out, q_len, t, dh, dc, dgates, B, H);
   return check_hip(hipGetLastError(), "lstm_cell_bwd launch");
 }
-
-#define DISPATCH_G(G, ...)                                         \
-  switch (G) {                                                     \
-    case 1: { constexpr int kG = 1; __VA_ARGS__; } break;          \
-    case 2: { constexpr int kG = 2; __VA_ARGS__; } break;          \
-    case 3: { constexpr int kG = 3; __VA_ARGS__; } break;          \
-    case 4: { constexpr int kG = 4; __VA_ARGS__; } break;          \
-    default: set_error("glimpses=%d unsupported (1..4)", G); return VQA_ERR_INVALID; \
-  }
 
 int vqa_att_score_fwd(const void* xs, int xs_is_bf16, const float* wx, int wx_ld, const float* bx, float* score, int B,
                       int P, int mid, int G, float p, uint64_t seed, const float* qcat, vqa_stream_t stream) {
@@ -955,7 +998,7 @@ int vqa_att_apply_bwd(const float* dout, int64_t dout_ld, const float* probs, co
                       float* dvn, float* dscore_rowsum, int B, int P, int C, int G, vqa_stream_t stream) {
   set_launch_tag(-1);
   ProfScope prof(VQA_K_ATT_APPLY_BWD, (hipStream_t)stream);
-  VQA_REQUIRE(dout && probs && vn && dscore && dvn && C % 4 == 0 && dout_ld % 4 == 0, "vqa_att_apply_bwd: bad args");
+  VQA_REQUIRE(dout && probs && vn && dscore && C % 4 == 0 && dout_ld % 4 == 0, "vqa_att_apply_bwd: bad args");
   const int64_t M = (int64_t)B * P;
   DISPATCH_G(G, hipLaunchKernelGGL(att_apply_bwd_rows_kernel<kG>, dim3(grid_for(M, 4)), dim3(256), 0, STREAM, dout,
                                    dout_ld, probs, vn, dscore, dvn, M, P, C));

@@ -451,7 +451,11 @@ class Engine:
 
         # ---- attention apply + scores
         ds_rows = new(B, G, 1)
-        dscore, dvn = ops.att_apply_bwd(dcomb, Dc, ctx.probs, ctx.vn, rowsum=ds_rows)
+        # d loss / d vn has two branches -- the weighted sum (probs x dcomb) and attention.drop(v) -> v_conv -- and one reader,
+        # the L2-norm backward: it joins them itself (VQA_JOIN_DVN=0: the three-kernel form att_apply_bwd -> dropout_add ->
+        # l2norm_bwd through a [B*P][C] fp32 tensor)
+        join = os.environ.get("VQA_JOIN_DVN", "1") != "0"
+        dscore, dvn = ops.att_apply_bwd(dcomb, Dc, ctx.probs, ctx.vn, rowsum=ds_rows, want_dvn=not join)
         ops.sum_bgp(ds_rows, Gr["attention.x_conv.bias"])       # x_conv bias gradient: sum over samples of the row sums
         wx = P["attention.x_conv.weight"].view(G, -1)
         dwx_part, dq_part, RS = ops.att_score_bwd(dscore, wx, ctx.xs, B, Pn, ctx.p_att, sd(SITE_ATT_X),
@@ -467,7 +471,10 @@ class Engine:
             dx16 = dxpre
             ops.gemm_bf16(dx16, ctx.v16.view(B * Pn, C), Gr["attention.v_conv.weight"].view(mid, C), mid, C, B * Pn,
                           transA=True, transB=False, lda=mid, ldb=C, tag=44)
-            if ctx.p_att > 0:       # dvn += dropout-mask * (dx' . Wv): one pass joins the two branches
+            if join:
+                dv_in = new(B * Pn, C)
+                ops.gemm_bf16(dx16, ctx.wv16, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
+            elif ctx.p_att > 0:     # dvn += dropout-mask * (dx' . Wv): one pass joins the two branches
                 dv_in = new(B * Pn, C)
                 ops.gemm_bf16(dx16, ctx.wv16, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45)
                 ops.dropout_add(dv_in, dvn, ctx.p_att, sd(SITE_ATT_V))
@@ -478,7 +485,10 @@ class Engine:
             gx3 = self._x3_gemm(B * Pn)
             ops.gemm(dxpre, ctx.v_in, Gr["attention.v_conv.weight"], mid, C, B * Pn, transA=True, transB=False, lda=mid,
                      ldb=C, tag=44, x3=gx3)
-            if ctx.p_att > 0:       # dvn += dropout-mask * (dx' . Wv): one pass joins the two branches
+            if join:
+                dv_in = new(B * Pn, C)
+                ops.gemm(dxpre, wv, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45, x3=gx3)
+            elif ctx.p_att > 0:     # dvn += dropout-mask * (dx' . Wv): one pass joins the two branches
                 dv_in = new(B * Pn, C)
                 ops.gemm(dxpre, wv, dv_in, B * Pn, C, mid, transB=False, lda=mid, ldb=C, tag=45, x3=gx3)
                 ops.dropout_add(dv_in, dvn, ctx.p_att, sd(SITE_ATT_V))
@@ -580,8 +590,14 @@ class Engine:
             main.wait_event(ev0)
 
         # ---- image: L2-norm (+dropout) backward, then conv blocks from the last to the first
-        if self.bf16 and ctx.use_pc:      # channel-blocked, as the routed patches of the backward kernels read it
-            dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE), c16_hw=tuple(ctx.idxs[-1].shape[2:4]))
+        c16_hw = tuple(ctx.idxs[-1].shape[2:4]) if self.bf16 and ctx.use_pc else None   # channel-blocked for the routed patches
+        if join:
+            dP = ops.l2norm_bwd_joined(dcomb, Dc, ctx.probs, dv_in, ctx.p_att, sd(SITE_ATT_V), ctx.vn, ctx.norm, ctx.p_img,
+                                       sd(SITE_IMAGE), out_dtype=torch.bfloat16 if self.bf16 else torch.float32, c16_hw=c16_hw)
+            if c16_hw is None:
+                dP = dP.view_as(ctx.acts[-1])
+        elif c16_hw is not None:
+            dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE), c16_hw=c16_hw)
         else:
             dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE),
                                 out_dtype=torch.bfloat16 if self.bf16 else torch.float32).view_as(ctx.acts[-1])

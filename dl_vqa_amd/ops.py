@@ -254,6 +254,27 @@ def l2norm_bwd(dvn, vn, norm, p: float, seed: int, out=None, out_dtype=torch.flo
     return d
 
 
+def l2norm_bwd_joined(dout, dout_ld, probs, dv_in, p_v: float, seed_v: int, vn, norm, p: float, seed: int,
+                      out_dtype=torch.float32, c16_hw=None):
+    """l2norm_bwd whose incoming gradient is joined in the kernel: sum_g probs[b,g,p] * dout[b, g*C:(g+1)*C] (what att_apply_bwd
+    would have written) + dropout_{p_v, seed_v}-mask * dv_in (what dropout_add would have added)."""
+    B, G, P = probs.shape
+    C = vn.shape[-1]
+    rows = vn.numel() // C
+    assert rows == B * P and dv_in.numel() == rows * C and dv_in.dtype == torch.float32
+    if c16_hw is not None:
+        Hp, Wp = c16_hw
+        assert Hp * Wp == P and C % 16 == 0
+        d = torch.empty(B, C // 16, Hp, Wp, 16, dtype=torch.bfloat16, device=vn.device)
+        mode = 2
+    else:
+        d = torch.empty(vn.shape, dtype=out_dtype, device=vn.device)
+        mode = int(out_dtype == torch.bfloat16)
+    call("vqa_l2norm_bwd_joined", ptr(dout), dout_ld, ptr(probs), G, ptr(dv_in), p_v, seed_v, ptr(vn), ptr(norm), ptr(d), mode,
+         rows, P, C, p, seed, stream())
+    return d
+
+
 def embed_tanh_fwd(q: torch.Tensor, emb: torch.Tensor, p: float, seed: int,
                    bad_tokens: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bad_tokens: optional device int32 [1], incremented once per token id outside [0, V)."""
@@ -351,12 +372,13 @@ def att_apply_fwd(score, vn, out, out_ld):
     return probs
 
 
-def att_apply_bwd(dout, dout_ld, probs, vn, dvn_out=None, rowsum=None):
-    """rowsum: optional [B, G] output, sum over positions of dscore (per-sample x_conv bias gradient)."""
+def att_apply_bwd(dout, dout_ld, probs, vn, dvn_out=None, rowsum=None, want_dvn=True):
+    """rowsum: optional [B, G] output, sum over positions of dscore (per-sample x_conv bias gradient).
+    want_dvn=False: the weighted-sum branch of d loss / d vn is not written (l2norm_bwd_joined recomputes it)."""
     B, G, P = probs.shape
     C = vn.shape[-1]
     dscore = torch.empty_like(probs)
-    dvn = dvn_out if dvn_out is not None else torch.empty_like(vn)
+    dvn = (dvn_out if dvn_out is not None else torch.empty_like(vn)) if want_dvn else None
     call("vqa_att_apply_bwd", ptr(dout), dout_ld, ptr(probs), ptr(vn), ptr(dscore), ptr(dvn), ptr(rowsum), B, P, C, G,
          stream())
     return dscore, dvn

@@ -155,6 +155,15 @@ int vqa_l2norm_bwd(const float* dvn, const float* vn, const float* norm, void* d
                                        channel-blocked [rows / positions][C/16][positions][16] for vqa_pconv_dgrad / _wgrad */,
                    int64_t rows, int positions /* rows per image: mode 2 only */, int C, float p, uint64_t seed,
                    vqa_stream_t stream);
+/* The same with the incoming gradient JOINED in the kernel instead of read from a [rows][C] tensor:
+ *   d loss / d vn [b*P + p][:] = sum_g probs[b][g][p] * dout[b][g*C : (g+1)*C]            (the weighted-sum branch, model.py:62:
+ *                                                                                          what vqa_att_apply_bwd writes as dvn)
+ *                               + dropout_{p_v, seed_v}-mask * dv_in[b*P + p][:]           (attention.drop on v, model.py:185:
+ *                                                                                          what vqa_dropout_add adds)
+ * -- two passes over a [B*P][C] fp32 tensor less per step; vqa_att_apply_bwd is then called with dvn = NULL. */
+int vqa_l2norm_bwd_joined(const float* dout, int64_t dout_ld, const float* probs, int G, const float* dv_in, float p_v,
+                          uint64_t seed_v, const float* vn, const float* norm, void* dpooled, int dpooled_mode, int64_t rows,
+                          int positions, int C, float p, uint64_t seed, vqa_stream_t stream);
 
 /* ---- question encoder (models/model.py:134-166 questionNet) ----------------------------------
  * x[t][b][:] = tanh(dropout(emb[q[b][t]]))   (embedding -> drop -> tanh, model.py:155-157).
@@ -230,7 +239,7 @@ int vqa_att_score_bwd(const float* dscore, const float* wx, int wx_ld, void* xs_
 /* probs = softmax_p(score); out[b*out_ld + g*C + c] = sum_p probs[b][g][p] * vn[b][p][c] */
 int vqa_att_apply_fwd(const float* score, const float* vn, float* probs, float* out, int64_t out_ld,
                       int B, int P, int C, int G, vqa_stream_t stream);
-/* dscore[b][g][p] and dvn[b][p][c] (written) from dout[b*dout_ld + g*C + c]; dscore_rowsum (optional)
+/* dscore[b][g][p] and dvn[b][p][c] (written; NULL: skipped, see vqa_l2norm_bwd_joined) from dout[b*dout_ld + g*C + c]; dscore_rowsum (optional)
  * [b][g] = sum_p dscore[b][g][p], the per-sample part of the x_conv bias gradient. */
 int vqa_att_apply_bwd(const float* dout, int64_t dout_ld, const float* probs, const float* vn,
                       float* dscore, float* dvn, float* dscore_rowsum, int B, int P, int C, int G,

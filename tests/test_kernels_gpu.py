@@ -263,6 +263,40 @@ def test_l2norm_second_output_and_dropout_add():
     assert float((acc - want).abs().max()) <= 1e-6 * float(want.abs().max())      # fused multiply-add vs two roundings
 
 
+@pytest.mark.parametrize("B,Hp,Wp,C,G,p_v,p", [(3, 5, 7, 64, 2, 0.3, 0.2), (2, 4, 4, 256, 1, 0.0, 0.0), (5, 3, 9, 128, 4, 0.5, 0.0)])
+def test_l2norm_bwd_joined_equals_the_three_kernel_form(B, Hp, Wp, C, G, p_v, p):
+    """vqa_l2norm_bwd_joined (d loss / d vn joined in the kernel from probs x dcomb and dropout-mask x dv_in) against
+    att_apply_bwd -> dropout_add -> l2norm_bwd through the [B*P][C] tensor: fp32, bf16 and channel-blocked bf16 outputs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 100 + C)
+    P = Hp * Wp
+    u = torch.randn(B * P, C, generator=g).to(DEV)
+    vn, norm = ops.l2norm_fwd(u, 0.0, 0)
+    probs = torch.softmax(torch.randn(B, G, P, generator=g), dim=2).to(DEV)
+    ld = G * C + 8
+    dcomb = torch.randn(B, ld, generator=g).to(DEV)
+    dv_in = torch.randn(B * P, C, generator=g).to(DEV)
+    dscore, dvn = ops.att_apply_bwd(dcomb, ld, probs, vn.view(B, P, C))
+    dscore2, none = ops.att_apply_bwd(dcomb, ld, probs, vn.view(B, P, C), want_dvn=False)
+    assert none is None
+    dvn = dvn.view(B * P, C)
+    if p_v > 0:
+        ops.dropout_add(dv_in, dvn, p_v, 991)
+    else:
+        dvn += dv_in
+    torch.cuda.synchronize()
+    assert torch.equal(dscore, dscore2)
+    for kw in ({"out_dtype": torch.float32}, {"out_dtype": torch.bfloat16}, {"c16_hw": (Hp, Wp)}):
+        want = ops.l2norm_bwd(dvn, vn, norm, p, 55, **kw)
+        got = ops.l2norm_bwd_joined(dcomb, ld, probs, dv_in, p_v, 991, vn, norm, p, 55, **kw)
+        torch.cuda.synchronize()
+        if got.dtype == torch.float32:      # the join is a fused multiply-add where dropout_add rounds twice
+            assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()), kw
+        else:
+            assert float((got.float() - want.float()).abs().max()) <= 2 ** -7 * float(want.float().abs().max()), kw
+            assert float((got != want).float().mean()) < 0.02, kw
+
+
 def test_embed_tanh_fwd_bwd():
     ops = _ops()
     g = torch.Generator().manual_seed(4)

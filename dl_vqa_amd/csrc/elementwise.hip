@@ -358,6 +358,76 @@ __global__ void att_score_fwd_kernel(const void* xs, const float* wx, int wx_ld,
   }
 }
 
+// The bf16 path's form of the above (x = relu(v' (+|*) q') stored as bf16, no concatenated half, mid <= 1024): the generic
+// kernel walked a row in four dependent rounds of 8-byte loads and re-read the x_conv weights for every row -- 2.3 TB/s.  Here
+// a lane owns 8 channels per round (16-byte loads), keeps its weights in registers for the whole kernel, and a wave has the
+// loads of TWO rows in flight before it touches the first value.
+template <int G>
+__global__ __launch_bounds__(256) void att_score_fwd_bf16_kernel(const uint16_t* xs, const float* wx, int wx_ld, const float* bx,
+                                                                 float* score, int64_t M, int P, int mid, float p, float inv_keep,
+                                                                 uint64_t seed) {
+  constexpr int IT = 2;                                   // rounds of 64 lanes x 8 channels: mid <= 1024
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int n8 = mid >> 3;
+  float w[IT][G][8];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c8 = lane + 64 * i;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[i][g][k] = c8 < n8 ? wx[(int64_t)g * wx_ld + 8 * c8 + k] : 0.f;
+  }
+  float bias[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bias[g] = bx[g];
+  for (int64_t m0 = 2 * wave; m0 < M; m0 += 2 * nwaves) {
+    uint4 xr[2][IT];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int c8 = lane + 64 * i;
+        xr[rr][i] = (m0 + rr < M && c8 < n8) ? *reinterpret_cast<const uint4*>(xs + (m0 + rr) * mid + 8 * c8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int64_t m = m0 + rr;
+      float acc[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = 0.f;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int c8 = lane + 64 * i;
+        const uint32_t u[4] = {xr[rr][i].x, xr[rr][i].y, xr[rr][i].z, xr[rr][i].w};
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[2 * k] = __uint_as_float(u[k] << 16); x[2 * k + 1] = __uint_as_float(u[k] & 0xffff0000u); }
+        if (p > 0.f) {
+          const uint64_t e = (uint64_t)m * mid + 8 * c8;
+          const float4 s0 = drop_scale4(seed, e, p, inv_keep), s1 = drop_scale4(seed, e + 4, p, inv_keep);
+          x[0] *= s0.x; x[1] *= s0.y; x[2] *= s0.z; x[3] *= s0.w; x[4] *= s1.x; x[5] *= s1.y; x[6] *= s1.z; x[7] *= s1.w;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[g] += x[k] * w[i][g][k];
+      }
+      if (m < M) {
+        const int64_t b = m / P;
+        const int pp = (int)(m - b * P);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float v = wave_sum(acc[g]);
+          if (lane == 0) score[(b * G + g) * P + pp] = v + bias[g];
+        }
+      }
+    }
+  }
+}
+
 // grid (B, RS); thread -> float4 column chunks; loops the rows of its split.
 // mode 0 '+': xs <- dz = (x>0) * mask * sum_g ds*wx            dq' part = sum_p dz
 // mode 1 '*': xs <- dv' = dz * q'[b]                             dq' part = sum_p dz * v'
@@ -941,7 +1011,10 @@ int vqa_att_score_fwd(const void* xs, int xs_is_bf16, const float* wx, int wx_ld
   VQA_REQUIRE(xs && wx && bx && score && mid % 4 == 0 && wx_ld % 4 == 0 && wx_ld >= (qcat ? 2 * mid : mid),
               "vqa_att_score_fwd: bad args");
   const int64_t M = (int64_t)B * P;
-  if (xs_is_bf16) {
+  if (xs_is_bf16 && !qcat && mid % 8 == 0 && mid <= 1024 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0) {
+    DISPATCH_G(G, hipLaunchKernelGGL((att_score_fwd_bf16_kernel<kG>), dim3(grid_for(M, 8)), dim3(256), 0, STREAM,
+                                     static_cast<const uint16_t*>(xs), wx, wx_ld, bx, score, M, P, mid, p, KEEP(p), seed));
+  } else if (xs_is_bf16) {
     DISPATCH_G(G, hipLaunchKernelGGL((att_score_fwd_kernel<kG, true>), dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx,
                                      wx_ld, bx, score, M, P, mid, p, KEEP(p), seed, qcat));
   } else {

@@ -87,11 +87,12 @@ def test_gemm_bf16_epilogue_and_bf16_output():
     assert torch.equal(Cb.cpu(), Cf.cpu().to(torch.bfloat16))        # the bf16 result is the rounded fp32 result
 
 
-@pytest.mark.parametrize("Bn,P,K,N,op", [(8, 676, 256, 1024, 0), (3, 2916, 256, 256, 1), (40, 300, 64, 512, 0), (17, 1000, 192, 128, None)])
+@pytest.mark.parametrize("Bn,P,K,N,op", [(8, 676, 256, 1024, 0), (3, 2916, 256, 256, 1), (40, 300, 192, 512, 0), (17, 1000, 64, 128, None),
+                                         (33, 2916, 512, 384, 1), (9, 4000, 128, 1024, None)])
 def test_gemm_tall_bf16(Bn, P, K, N, op):
     """csrc/gemm_tall_bf16.hip (persistent 256 x 128 tiles, short K) against the float64 product of the bf16-rounded
     operands: row-group add / multiply / none, ReLU, tiles that span two groups, a last row tile that is partly past M,
-    several tiles per workgroup.  The result must equal the rounded fp32 result of vqa_gemm_bf16 up to summation order."""
+    several tiles per workgroup (the three-stage ring crosses tile boundaries), one to eight k-stages per tile.  The result must equal the rounded fp32 result of vqa_gemm_bf16 up to summation order."""
     ops = _ops()
     M = Bn * P
     assert ops.gemm_tall_bf16_supported(M, N, K, P, op is not None)

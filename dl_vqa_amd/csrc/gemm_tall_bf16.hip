@@ -7,44 +7,45 @@
 //   * persistent workgroups (one per CU) walk 256 x 128 tiles, N fastest, so the eight column tiles of a row block follow
 //     each other and its A rows come from L2 after the first;
 //   * 8 waves, all computing: 4 (M) x 2 (N) waves of 64 x 64 = 2 x 2 accumulators of v_mfma_f32_32x32x16_bf16;
-//   * a stage = 64 of K: A 256 rows x 128 B + W 128 rows x 128 B = 48 pieces of 1 KiB, fetched by LDS-DMA (inline asm, see
-//     conv_patch_bf16.hip) TWO stages ahead (three stage buffers), ACROSS tile boundaries, six pieces per wave interleaved
-//     with its 16 MFMAs; one counted s_waitcnt + one s_barrier per stage;
-//   * LDS image: rows of 128 bytes, 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7) (applied to the DMA's per-lane
-//     source address and to the fragment read): the 16 rows of a ds_read_b128 lane group then cover all 16 bank groups;
-//   * epilogue per tile: row-group term (two groups at most per tile: rg_div >= 256; the tile's terms arrive as one more DMA
-//     piece in a 1-KiB LDS table), ReLU, bf16, through a wave-private LDS scratch, 16 bytes per lane to HBM (whole 128-byte runs).
+//   * a stage = 64 of K: A 256 rows x 128 B + W 128 rows x 128 B = 48 pieces of 1 KiB, six per wave, fetched TWO stages ahead
+//     through registers (see the note at the kernel), ACROSS tile boundaries; one s_barrier per stage;
+//   * LDS image: rows of 128 bytes, 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7) (applied where the piece is stored
+//     and to the fragment read): the 16 rows of a ds_read_b128 lane group then cover all 16 bank groups;
+//   * epilogue per tile: row-group term (two groups at most per tile: rg_div >= 256; the tile's terms travel like one more
+//     piece into a 1-KiB LDS table), ReLU, bf16, through a wave-private LDS scratch, 16 bytes per lane to HBM (whole 128-byte runs).
 // Arithmetic intensity bounds this shape below the matrix peak (128 flop per byte of A): ~50 % is the ceiling.
 #include "bf16_core.hpp"
+#include <stdlib.h>
 
 namespace vqa {
 
-typedef unsigned int tg_rsrc_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ tg_rsrc_t tg_rsrc(const void* base, uint32_t bytes = 0xffff0000u) {
-  const uint64_t a = (uint64_t)base;
-  tg_rsrc_t r;
-  r.x = __builtin_amdgcn_readfirstlane((uint32_t)a);
-  r.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
-  r.z = __builtin_amdgcn_readfirstlane(bytes);
-  r.w = 0x00020000u;
-  return r;
-}
-// 16 bytes per lane, global -> LDS without a VGPR round trip; invisible to hipcc's wait insertion (the kernel counts)
-__device__ __forceinline__ void tg_dma16(tg_rsrc_t r, const void* lds_dst, uint32_t voff, uint32_t soff) {
-  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst);
-  uint32_t keep;
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(m0v), "v"(voff), "s"(r), "s"(soff) : "memory");
-}
+// Timing experiments (tools/kbench_tall.py --dbg ...): only a -DVQA_TALL_DIAG build looks at VQA_TALL_DBG (1 = no epilogue,
+// 2 = no stage traffic after the prologue, 4 = no MFMA, 8 = every tile's stores go to tile 0's rows (the write stream stays in
+// L2), 16 = the epilogue's arithmetic without its stores); the shipped kernel carries none of those branches.
+#ifdef VQA_TALL_DIAG
+#define TG_DBG(bit) (P.dbg & (bit))
+#else
+#define TG_DBG(bit) false
+#endif
 
-constexpr int TG_BM = 256, TG_BN = 128, TG_BK = 64;
-constexpr int TG_A = TG_BM * 128;                 // bytes of an A stage (256 rows x 64 bf16)
+constexpr int TG_BN = 128, TG_BK = 64;
 constexpr int TG_B = TG_BN * 128;
-constexpr int TG_STAGE = TG_A + TG_B;             // 48 KiB
-constexpr int TG_NST = 3;                         // stages in LDS: two in flight while one is computed
-constexpr int TG_SCR = 8 * 128;                   // epilogue scratch per wave: 8 rows x 64 bf16
 constexpr int TG_TAB = 1024;                      // row-group terms of the tile: [2 groups][128 columns] fp32
-constexpr int TG_LDS = TG_NST * TG_STAGE + 8 * TG_SCR + TG_TAB;   // 153 KiB
+// WMW waves along M (64 rows each) x 2 along N: 4 -> 256 x 128 tiles, one workgroup of 8 waves per CU; 2 -> 128 x 128 tiles,
+// TWO workgroups of 4 waves per CU.  Measured with the parts switched off (tools/kbench_tall.py, 1.49 M x 1024 x 256): barriers +
+// fragment reads 0.31 ms, + MFMAs 0.62, stage traffic alone 0.45, epilogue arithmetic 0.2, its stores 0.1 into L2 and 0.5 into
+// HBM -- and the times ADD (1.7 ms all together) for either workgroup shape, staggered starts included: what a tile costs is
+// the sum of its phases' latencies, not the busiest unit.  DESIGN.md section 4.3 has the table.
+template <int WMW>
+struct TgCfg {
+  static constexpr int BM = 64 * WMW, NW = 2 * WMW;
+  static constexpr int A = BM * 128;              // bytes of an A stage (BM rows x 64 bf16)
+  static constexpr int STAGE = A + TG_B;
+  static constexpr int PA = BM / 8;               // 1-KiB pieces of the A stage; 16 of the W stage
+  static constexpr int NP = (PA + 16) / NW;       // pieces per wave: 6 / 8, the first 4 of them A
+  static_assert(PA == 4 * NW, "piece q of a wave is an A piece for q < 4");
+  static constexpr int LDS = 2 * STAGE + TG_TAB;                 // 97 / 65 KiB
+};
 
 struct TgParams {
   const char* A; const char* A_end; int64_t lda;   // bf16 [M][K], lda in elements
@@ -53,15 +54,22 @@ struct TgParams {
   const float* rg; int64_t rg_ld; int rg_div; int rg_op; int rg_groups;   // optional row-group term (add / mul), groups of rg_div rows
   int relu;
   int M, N, K, tiles_m, tiles_n, nk;
+  int dbg;
 };
 
-// Stage ring.  With two stages (round-3 first version) the pieces of stage g + 1 were issued DURING stage g and waited for at its
-// end: half a stage (~0.3 us) of lead against ~1-2 us of HBM latency -- every stage ended in a stall, 1.96 ms per launch where
-// the HBM time is 0.9 ms.  Three stages: the pieces of stage g + 2 are issued during stage g; the wait at the top of stage
-// g + 1 is COUNTED (the six pieces of stage g + 2 this wave issued last may still be in flight).  Every wave issues exactly six
-// pieces per stage (out-of-range ones past the last tile: the hardware range check drops them), so the counts are constants;
-// wave 0 adds the 1-KiB row-group table of a tile (nk >= 3 with row groups).
-__global__ __launch_bounds__(512, 2) void gemm_tall_bf16_kernel(const TgParams P) {
+// How the stages reach LDS.  A stage is 48 pieces of 1 KiB for 128 MFMAs: far more bytes per MFMA than the convolutions move,
+// and the LDS-DMA form (buffer_load ... lds, one piece per instruction) is slow to ISSUE -- a few hundred cycles per instruction
+// (conv_patch_bf16.hip hides nine of them behind 72 MFMAs per wave; here six stood against 16 MFMAs): with DMA, two or three
+// stage buffers alike, the kernel sat at 1.7-2.0 ms per launch, 20 k cycles per tile where MFMAs + epilogue are ~8 k, with HBM
+// traffic at the compulsory 3.8 GB (PMC).  So the pieces travel through REGISTERS: a wave loads its six pieces of stage g + 2
+// (24 VGPRs) at the top of stage g, writes them into the free stage buffer at the top of stage g + 1 (ds_write_b128: 13 cycles
+// per KiB), and they are read as stage g + 2 -- two LDS buffers, registers as the third, one s_barrier per stage, hipcc's own
+// vmcnt bookkeeping (the loads are a full stage old when their registers are read; a second register set, two stages ahead, was
+// slower: 2.1 ms).
+template <int WMW>
+__global__ __launch_bounds__(128 * WMW, 2) void gemm_tall_bf16_kernel(const TgParams P) {
+  using C = TgCfg<WMW>;
+  constexpr int TG_BM = C::BM, TG_A = C::A, TG_STAGE = C::STAGE, NP = C::NP;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -83,49 +91,46 @@ __global__ __launch_bounds__(512, 2) void gemm_tall_bf16_kernel(const TgParams P
       aoff[i][s] = (uint32_t)(ra * 128 + (((2 * s + h) ^ ((ra >> 1) & 7)) << 4));
       boff[i][s] = (uint32_t)(TG_A + rb * 128 + (((2 * s + h) ^ ((rb >> 1) & 7)) << 4));
     }
-  // ---- DMA pieces of this wave: piece p = wave + 8 q (q = 0..5): p < 32 -> A rows 8p.., else W rows 8(p-32)..
-  uint32_t voff[6];
+  // ---- pieces of this wave: piece p = wave + NW q (q = 0..NP-1): p < PA (q < 4) -> A rows 8p.., else W rows 8(p-PA)..; a lane
+  // takes the 16-byte chunk (lane & 7) of row (lane >> 3) and stores it at slot chunk ^ ((row >> 1) & 7) of its 128-byte LDS row
+  uint32_t voff[NP], loff[NP];
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const int p = wave + 8 * q;
-    const int row = (p < 32 ? 8 * p : 8 * (p - 32)) + (lane >> 3), slot = lane & 7;
-    const int chunk = slot ^ ((row >> 1) & 7);
-    voff[q] = (uint32_t)(row * (p < 32 ? (int)P.lda : (int)P.ldw) * 2 + chunk * 16);
+  for (int q = 0; q < NP; ++q) {
+    const int p = wave + C::NW * q;
+    const int row = (q < 4 ? 8 * p : 8 * (p - C::PA)) + (lane >> 3), chunk = lane & 7;
+    voff[q] = (uint32_t)(row * (q < 4 ? (int)P.lda : (int)P.ldw) * 2 + chunk * 16);
+    loff[q] = (uint32_t)((q < 4 ? 0 : TG_A) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
   }
-  char* const tab = smem + TG_NST * TG_STAGE + 8 * TG_SCR;
+  char* const tab = smem + 2 * TG_STAGE;
 
-  // the stage being fetched: two ahead of the one being computed
-  tg_rsrc_t ns_a = tg_rsrc(P.A, 0u), ns_w = tg_rsrc(P.W, 0u);
-  uint32_t ns_k = 0;
-  int ns_buf = 0;
+  float4 pr[NP];                                    // the pieces in flight
+  float4 tr = make_float4(0.f, 0.f, 0.f, 0.f);      // wave 0: the row-group table piece in flight
   int ft = 0, fks = 0, fcount = 0;                  // fetch cursor: tile number (of mine), k-stage, stages fetched so far
-  auto set_fetch = [&]() {
+  auto load_stage = [&]() {                         // past the last stage: zero-byte resources, the loads return zeros
     const bool on = fcount < nstages;
     const int tile = first + ft * (int)gridDim.x;
     const int mt = tile / P.tiles_n, nt = tile - mt * P.tiles_n;
     const char* a = P.A + (int64_t)mt * TG_BM * P.lda * 2;
     const int64_t left = P.A_end - a;                       // rows past M read zeros (range check)
-    ns_a = tg_rsrc(a, !on || left <= 0 ? 0u : left > 0xffff0000LL ? 0xffff0000u : (uint32_t)left);
-    ns_w = tg_rsrc(P.W + (int64_t)nt * TG_BN * P.ldw * 2, on ? 0xffff0000u : 0u);
-    ns_k = (uint32_t)(fks * TG_BK * 2);
-    ns_buf = fcount % TG_NST;
-  };
-  auto advance_fetch = [&]() {
+    const __amdgpu_buffer_rsrc_t ra = buf_rsrc(a, !on || left <= 0 ? 0u : left > 0xffff0000LL ? 0xffff0000u : (uint32_t)left);
+    const __amdgpu_buffer_rsrc_t rw = buf_rsrc(P.W + (int64_t)nt * TG_BN * P.ldw * 2, on ? 0xffff0000u : 0u);
+    const uint32_t ko = (uint32_t)(fks * TG_BK * 2);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) pr[q] = buf_load16(q < 4 ? ra : rw, voff[q], ko);
     ++fcount;
     if (++fks == P.nk) { fks = 0; ++ft; }
   };
-  auto issue_piece = [&](int q) {          // always issued: the counted waits rely on six per wave and stage
-    const int p = wave + 8 * q;
-    if (p < 32) tg_dma16(ns_a, smem + ns_buf * TG_STAGE + p * 1024, voff[q], ns_k);
-    else tg_dma16(ns_w, smem + ns_buf * TG_STAGE + TG_A + (p - 32) * 1024, voff[q], ns_k);
+  auto store_stage = [&](int buf) {
+    char* const st = smem + buf * TG_STAGE;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) *reinterpret_cast<float4*>(st + loff[q]) = pr[q];
   };
   // row-group table of a tile (wave 0): lanes 0-31 the tile's first group, 32-63 the next one, 4 columns each
-  auto issue_table = [&](int tile) {
+  auto load_table = [&](int tile) {
     const int mt = tile / P.tiles_n, nt = tile - mt * P.tiles_n;
     const int g0 = (mt * TG_BM) / P.rg_div + (lane >> 5);
-    const tg_rsrc_t rr = tg_rsrc(P.rg, P.rg ? 0xffff0000u : 0u);
-    const uint32_t vo = g0 < P.rg_groups ? (uint32_t)(((int64_t)g0 * P.rg_ld + nt * TG_BN + 4 * (lane & 31)) * 4) : 0xffff0000u;
-    tg_dma16(rr, tab, vo, 0u);
+    const __amdgpu_buffer_rsrc_t rr = buf_rsrc(P.rg);
+    tr = buf_load16(rr, g0 < P.rg_groups ? (uint32_t)(((int64_t)g0 * P.rg_ld + nt * TG_BN + 4 * (lane & 31)) * 4) : BUF_OOB);
   };
 
   f32x16 acc[2][2];
@@ -138,107 +143,113 @@ __global__ __launch_bounds__(512, 2) void gemm_tall_bf16_kernel(const TgParams P
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   };
   zero_acc();
-  char* const scr = smem + TG_NST * TG_STAGE + wave * TG_SCR;
 
-  // prologue: stages 0 and 1 in flight
-#pragma unroll
-  for (int pre = 0; pre < 2; ++pre) {
-    set_fetch();
-#pragma unroll
-    for (int q = 0; q < 6; ++q) issue_piece(q);
-    advance_fetch();
-  }
+  // prologue: stage 0 into buffer 0, stage 1 into the registers
+  load_stage();
+  store_stage(0);
+  load_stage();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int buf = 0;
-  // VMEM operations this wave issued AFTER the pieces of the stage it waits for next (they may stay in flight): wait_n; the
-  // same for the stage after it: younger.  Updated as pieces, the table and the epilogue stores go out (all wave-uniform).
-  int wait_n = 6, younger = 0;
   for (int t = 0; t < my_tiles; ++t) {
     const int tile = first + t * (int)gridDim.x;
     const int mt = tile / P.tiles_n, nt = tile - mt * P.tiles_n;
     const int m0 = mt * TG_BM, n0 = nt * TG_BN;
     for (int ks = 0; ks < P.nk; ++ks) {
-      // this wave's pieces of the current stage have landed (s_waitcnt takes an immediate: the counts that occur are 6 / 7 between
-      // stages, + 8 across an epilogue; anything else waits for everything)
-      switch (wait_n) {
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      __builtin_amdgcn_s_barrier();                 // stage (t, ks) is in LDS for everybody; the other buffer is free
+      // the registers hold the next stage (loaded a stage ago): into the free buffer, then the loads of the stage after it
+      // the registers hold the next stage (loaded a stage ago): into the free buffer, then the loads of the stage after it
+      if (!TG_DBG(2)) store_stage(buf ^ 1);
+      if (wave == 0 && P.rg) {
+        // the tile's row-group table: loaded with stage nk - 3, stored with stage nk - 2, so that the barrier of the tile's last
+        // stage shows it to everybody before the epilogue (its previous reader, the previous tile's epilogue, is long done)
+        if (ks == P.nk - 2) *reinterpret_cast<float4*>(tab + lane * 16) = tr;
+        if (ks == P.nk - 3) load_table(tile);
       }
-      __builtin_amdgcn_s_barrier();
-      // the tile's row-group table goes out BEFORE the pieces issued in this stage (those of the tile's last stage when
-      // ks == nk - 3): the wait at the top of that last stage then covers it, the barrier behind the wait shows it to everybody;
-      // its previous reader, the previous tile's epilogue, is behind every wave that passed this barrier
-      if (wave == 0 && P.rg && ks == P.nk - 3) { issue_table(tile); ++younger; }
-      set_fetch();
+      if (!TG_DBG(2)) load_stage();
+      __builtin_amdgcn_sched_barrier(0);
       const char* const st = smem + buf * TG_STAGE;
-      bf16x8 a[2], b[2];
+      // fragments of k-step s + 1 are read while the MFMAs of k-step s run.  The accumulators are TRANSPOSED (W rows as the A
+      // operand): lane (r, h) holds row r of the 32-row block, 4 consecutive columns per register group -- the epilogue packs
+      // them to 8 bytes and never goes through LDS
+      bf16x8 a[2][2], b[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[0][i] = *reinterpret_cast<const bf16x8*>(st + aoff[i][0]);
+        b[0][i] = *reinterpret_cast<const bf16x8*>(st + boff[i][0]);
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        if (s < 3) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[i] = *reinterpret_cast<const bf16x8*>(st + aoff[i][s]);
-          b[i] = *reinterpret_cast<const bf16x8*>(st + boff[i][s]);
+          for (int i = 0; i < 2; ++i) {
+            a[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(st + aoff[i][s + 1]);
+            b[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(st + boff[i][s + 1]);
+          }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (!TG_DBG(4)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_piece(s);
-        if (s >= 2) issue_piece(s + 2);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[s & 1][j], a[s & 1][i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(a[s & 1][i]), "v"(b[s & 1][i]));
+        }
       }
-      advance_fetch();
-      wait_n = younger + 6;          // the next stage's pieces are older than this stage's table piece and the six just issued
-      younger = 0;
-      buf = buf + 1 == TG_NST ? 0 : buf + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      // the ds_writes above must have landed before the next barrier lets others read them
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      buf ^= 1;
     }
-    // ---- epilogue of the tile: (+|*) row-group term, ReLU, bf16, through the wave's scratch in rounds of 8 rows
+    if (TG_DBG(1)) {
+      if (acc[0][0][0] == 123.456f) P.C[0] = 1;      // keeps the accumulators alive
+      zero_acc();
+      continue;
+    }
+    // ---- epilogue of the tile: (+|*) row-group term, ReLU, bf16, straight from the registers.  Lane (r, h) holds, of row r, the
+    // columns 8 c + 4 h .. + 3 of every 8-column chunk c; one v_permlane32_swap per register hands the lower lanes the whole
+    // even chunks and the upper lanes the whole odd ones: 16-byte stores, four per 32-row block (the LDS round trip -- 64
+    // two-byte ds_writes per wave and tile -- was 0.5-0.9 ms of this kernel's 1.9)
     const bool mul = P.rg_op != 0, relu = P.relu != 0;
-    float rgv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     const int g0 = P.rg ? m0 / P.rg_div : 0;
     const int boundary = (g0 + 1) * P.rg_div;
-    if (P.rg) {
-#pragma unroll
-      for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) rgv[gg][j] = *reinterpret_cast<const float*>(tab + (gg * 128 + wn * 64 + 32 * j + r) * 4);
-    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      const int row = m0 + wm * 64 + 32 * i + r;
+      const char* const tb = tab + (row >= boundary ? 512 : 0) + (wn * 64 + 4 * h) * 4;
+      uint32_t G[8][2];
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int rbase = m0 + wm * 64 + 32 * i + 8 * q4;         // the round's 8 rows: rbase + 4 h + (e & 3)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float v[4];
 #pragma unroll
-          for (int e4 = 0; e4 < 4; ++e4) {
-            float v = acc[i][j][4 * q4 + e4];
-            if (P.rg) {
-              const float tt = rbase + 4 * h + e4 < boundary ? rgv[0][j] : rgv[1][j];
-              v = mul ? v * tt : v + tt;
-            }
-            if (relu) v = fmaxf(v, 0.f);
-            *reinterpret_cast<uint16_t*>(scr + (4 * h + e4) * 128 + (32 * j + r) * 2) = bf16_bits(v);
+          for (int e4 = 0; e4 < 4; ++e4) v[e4] = acc[i][j][4 * q4 + e4];
+          if (P.rg) {
+            const float4 tt = *reinterpret_cast<const float4*>(tb + (32 * j + 8 * q4) * 4);
+            if (mul) { v[0] *= tt.x; v[1] *= tt.y; v[2] *= tt.z; v[3] *= tt.w; }
+            else { v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w; }
           }
-        asm volatile("" ::: "memory");
-        const __amdgpu_buffer_rsrc_t ro = buf_rsrc(P.C + (int64_t)rbase * P.ldc + n0 + wn * 64);
-        {
-          const int row = lane >> 3, inrow = (lane & 7) * 16;
-          const float4 v = *reinterpret_cast<const float4*>(scr + lane * 16);
-          const bool ok = rbase + row < P.M;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
-                                                 ok ? (int)((uint32_t)row * (uint32_t)P.ldc * 2u + inrow) : (int)BUF_OOB, 0, 0);
+          if (relu) {
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) v[e4] = fmaxf(v[e4], 0.f);
+          }
+          G[4 * j + q4][0] = pack_bf16x2(v[0], v[1]);
+          G[4 * j + q4][1] = pack_bf16x2(v[2], v[3]);
         }
-        asm volatile("" ::: "memory");
+      const __amdgpu_buffer_rsrc_t ro = TG_DBG(8) ? buf_rsrc(P.C + (int64_t)(wm * 64 + 32 * i) * P.ldc + wn * 64)
+                                                  : buf_rsrc(P.C + (int64_t)(m0 + wm * 64 + 32 * i) * P.ldc + n0 + wn * 64);
+      const uint32_t vo = row < P.M ? (uint32_t)r * (uint32_t)P.ldc * 2u + 16u * h : BUF_OOB;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(G[2 * k][0], G[2 * k + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(G[2 * k][1], G[2 * k + 1][1], false, false);
+        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        if (TG_DBG(16)) asm volatile("" ::"v"(o));
+        else __builtin_amdgcn_raw_buffer_store_b128(o, ro, (int)vo, 32 * k, 0);
       }
     }
-    wait_n += 8;                     // the eight stores: younger than the pieces of both stages in flight
-    younger += 8;
     zero_acc();
   }
 }
@@ -274,14 +285,30 @@ int vqa_gemm_tall_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, v
   P.rg = rowgroup; P.rg_ld = rg_ld; P.rg_div = rg_div > 0 ? rg_div : 1; P.rg_op = rg_op; P.relu = relu;
   P.rg_groups = (M + P.rg_div - 1) / P.rg_div;
   P.M = M; P.N = N; P.K = K;
-  P.tiles_m = (M + TG_BM - 1) / TG_BM; P.tiles_n = N / TG_BN; P.nk = K / TG_BK;
+  P.tiles_n = N / TG_BN; P.nk = K / TG_BK;
+  {
+    const char* e = getenv("VQA_TALL_DBG");
+    P.dbg = e ? atoi(e) : 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   set_launch_tag(tag);
   ProfScope prof(VQA_K_GEMM, s);
-  int rc = ensure_dyn_smem(reinterpret_cast<const void*>(gemm_tall_bf16_kernel), TG_LDS, "attr(gemm_tall_bf16)");
-  if (rc) return rc;
-  const int tiles = P.tiles_m * P.tiles_n;
-  hipLaunchKernelGGL(gemm_tall_bf16_kernel, dim3(tiles < 256 ? tiles : 256), dim3(512), TG_LDS, s, P);
+  // 256 x 128 tiles, one workgroup of eight waves per CU (1.68 ms at 1.49 M x 1024 x 256); VQA_TALL_BM=128: 128 x 128 tiles on two
+  // workgroups of four waves per CU (1.82 ms: the two do not hide each other's phases, and W is fetched twice as often)
+  static const int bm256 = [] { const char* e = getenv("VQA_TALL_BM"); return e && atoi(e) == 128 ? 0 : 1; }();
+  if (bm256) {
+    P.tiles_m = (M + 255) / 256;
+    int rc = ensure_dyn_smem(reinterpret_cast<const void*>(gemm_tall_bf16_kernel<4>), TgCfg<4>::LDS, "attr(gemm_tall_bf16)");
+    if (rc) return rc;
+    const int tiles = P.tiles_m * P.tiles_n;
+    hipLaunchKernelGGL(gemm_tall_bf16_kernel<4>, dim3(tiles < 256 ? tiles : 256), dim3(512), TgCfg<4>::LDS, s, P);
+  } else {
+    P.tiles_m = (M + 127) / 128;
+    int rc = ensure_dyn_smem(reinterpret_cast<const void*>(gemm_tall_bf16_kernel<2>), TgCfg<2>::LDS, "attr(gemm_tall_bf16)");
+    if (rc) return rc;
+    const int tiles = P.tiles_m * P.tiles_n;
+    hipLaunchKernelGGL(gemm_tall_bf16_kernel<2>, dim3(tiles < 512 ? tiles : 512), dim3(256), TgCfg<2>::LDS, s, P);
+  }
   return check_hip(hipGetLastError(), "gemm_tall_bf16 launch");
 }
 

@@ -21,8 +21,8 @@ def per_kernel(d, counter):
                 if short.startswith(k + "_"):     # conv_fwd_kernel, conv_fwd_bf16_kernel, ...
                     key = k
             # bf16 path (csrc/conv_patch_bf16.hip): pconv_kernel<WM, EPI> is the forward for EPI 0/1 (pooled output) and the
-            # backward-data for EPI 2/3; the weight gradient is pconv_wgrad_kernel (+ its split reduce, listed beside it)
-            m = re.match(r"pconv_kernel<\d+, (\d)>", short)
+            # backward-data for EPI 2/3/4; the weight gradient is pconv_wgrad_kernel (+ its split reduce, listed beside it)
+            m = re.match(r"pconv_kernel<\d+, (\d)[,>]", short)
             if m:
                 key = "conv_fwd" if m.group(1) in "01" else "conv_dgrad"
             elif short.startswith("pconv_wgrad_kernel"):

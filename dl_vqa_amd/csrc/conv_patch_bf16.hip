@@ -595,6 +595,7 @@ struct PwParams {
   const char* dp;                          // pooled gradient, C16 [B][Co/16][Hp][Wp][16] bf16
   const char* am;                          // arg-max bytes, C16 [B][Co/16][Hp][Wp][16]
   float* slabs;                            // [grid][9][64][128]
+  float* bslabs;                           // [grid][128]: bias-gradient partial sums (roles with ci0 == 0)
   int B, H, W, Ci, Co, Hp, Wp;
   int tiles_y, tiles_x, ntiles;            // 4 x 32-pixel tiles over the pool-covered map, per image / in all
   int roles_co, nroles;                    // Co / 128, (Ci / 64) * (Co / 128)
@@ -666,11 +667,25 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
     ++rt_count;
     rtt.advance(dlt, P.tiles_y, P.tiles_x);
   };
+  // bias gradient = sum of the pooled gradient over the live windows (arg-max code != 4): every (window, 8 channels) piece of dP
+  // passes through exactly one thread of every role here, so the roles with ci0 == 0 sum it on the way (8 fp32 per thread, combined
+  // over the wave's 32 windows at the end) -- the separate pass over dP + arg-max (0.6 ms per step at 448 x 448) is gone
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = ci0 == 0;
   auto rt_route = [&](int buf) {
     char* const dst = smem + buf * PW_STAGE + rt_dst;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<float4*>(dst + ((j >> 1) * 32 + (j & 1)) * 32) = pc_route8(rt_d, rt_a, (uint32_t)j);
+    if (want_bias) {
+      const uint32_t dd[4] = {__float_as_uint(rt_d.x), __float_as_uint(rt_d.y), __float_as_uint(rt_d.z), __float_as_uint(rt_d.w)};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t code = ((k < 4 ? rt_a.x : rt_a.y) >> (8 * (k & 3))) & 0xffu;
+        const uint32_t bits = (k & 1) ? (dd[k >> 1] & 0xffff0000u) : (dd[k >> 1] << 16);
+        bs[k] += __uint_as_float(bits & ((code >> 2) - 1u));           // codes 0..3 keep, 4 (dead window) clears
+      }
+    }
   };
 
   f32x16 acc[9];
@@ -729,6 +744,16 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
     }
     buf ^= 1;
   }
+  // ---- bias partial sums: lanes that share (block = wave, half) differ in lane bits 1..5
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) bs[k] += __shfl_xor(bs[k], o, 64);
+  }
+  if (lane < 2) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P.bslabs[(int64_t)bid * 128 + wave * 16 + lane * 8 + k] = bs[k];
+  }
   // ---- this workgroup's fp32 slab [tap][64 ci][128 co] (zeros when it had no tile)
   float* const slab = P.slabs + (int64_t)bid * (9 * 64 * 128);
   const int c = lane & 31;
@@ -741,11 +766,20 @@ __global__ __launch_bounds__(512, 2) void pconv_wgrad_kernel(const PwParams P) {
     }
 }
 
-// dw[co][ci][tap] = sum over the workgroups of role (ci / 64, co / 128) of slab[tap][ci % 64][co % 128], in workgroup order
-__global__ __launch_bounds__(256) void pconv_wgrad_reduce_kernel(const float* slabs, float* dw, int Ci, int Co, int grid,
-                                                                int nroles, int roles_co) {
+// dw[co][ci][tap] = sum over the workgroups of role (ci / 64, co / 128) of slab[tap][ci % 64][co % 128], in workgroup order;
+// the last Co threads: dbias[co] = sum over the workgroups of role (0, co / 128) of bslab[co % 128]
+__global__ __launch_bounds__(256) void pconv_wgrad_reduce_kernel(const float* slabs, const float* bslabs, float* dw, float* dbias,
+                                                                int Ci, int Co, int grid, int nroles, int roles_co) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (tap, ci, co), co fastest: coalesced slab reads
-  if (idx >= 9 * Ci * Co) return;
+  if (idx >= 9 * Ci * Co + Co) return;
+  if (idx >= 9 * Ci * Co) {
+    const int co = idx - 9 * Ci * Co, role = co / 128;
+    float s = 0.f;
+    for (int b = 0; b < grid; ++b)
+      if ((b >> 3) % nroles == role) s += bslabs[(int64_t)b * 128 + (co & 127)];
+    dbias[co] = s;
+    return;
+  }
   const int co = idx % Co, ci = (idx / Co) % Ci, tap = idx / (Co * Ci);
   const int role = (ci / 64) * roles_co + co / 128;
   const int off = (tap * 64 + (ci & 63)) * 128 + (co & 127);
@@ -753,58 +787,6 @@ __global__ __launch_bounds__(256) void pconv_wgrad_reduce_kernel(const float* sl
   for (int b = 0; b < grid; ++b)
     if ((b >> 3) % nroles == role) s += slabs[(int64_t)b * (9 * 64 * 128) + off];
   dw[((int64_t)co * Ci + ci) * 9 + tap] = s;
-}
-
-// bias gradient = column sums of the pooled gradient over the windows that are alive (arg-max != 4); two deterministic stages.
-// dP and the arg-max bytes are C16: a block takes one (image, 16-channel block) plane chunk, a thread 8 channels of a window
-// (16 bytes of dP + 8 bytes) with consecutive threads on consecutive 16-byte pieces; the 128 threads of a half are combined
-// through LDS in a fixed order.  part[chunk][Co], chunk = image * chunks_per_plane + c.
-__global__ __launch_bounds__(256) void pconv_bias_part_kernel(const uint16_t* dp, const uint8_t* am, float* part, int plane,
-                                                             int Co, int cpp, int per) {
-  __shared__ float bred[256][9];
-  const int chunk = blockIdx.x % cpp, blk = (blockIdx.x / cpp) % (Co / 16), b = blockIdx.x / (cpp * (Co / 16));
-  const int hf = threadIdx.x & 1;
-  const int64_t base = ((int64_t)b * (Co / 16) + blk) * plane;
-  const int w1 = (chunk + 1) * per < plane ? (chunk + 1) * per : plane;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int w = chunk * per + (threadIdx.x >> 1); w < w1; w += 128) {
-    const uint4 d = *reinterpret_cast<const uint4*>(dp + (base + w) * 16 + 8 * hf);
-    const uint2 a = *reinterpret_cast<const uint2*>(am + (base + w) * 16 + 8 * hf);
-    const uint32_t dd[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t code = ((k < 4 ? a.x : a.y) >> (8 * (k & 3))) & 0xffu;
-      const float v = (k & 1) ? bf16_hi(dd[k >> 1]) : bf16_lo(dd[k >> 1]);
-      acc[k] += code != 4u ? v : 0.f;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) bred[threadIdx.x][k] = acc[k];
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    const int c = threadIdx.x;                               // channel c of the block: half c / 8, element c % 8
-    float s = 0.f;
-    for (int l = 0; l < 128; ++l) s += bred[2 * l + (c >> 3)][c & 7];
-    part[((int64_t)b * cpp + chunk) * Co + blk * 16 + c] = s;
-  }
-}
-// dbias[co] = sum of the parts, in a fixed order: a block takes 32 channels, its 8 part lanes stride over the parts and
-// are combined through LDS (the one-thread-per-channel form was a chain of 1 024 dependent loads: 255 us)
-__global__ __launch_bounds__(256) void pconv_bias_reduce_kernel(const float* part, float* dbias, int parts, int Co) {
-  __shared__ float red[8][32];
-  const int c = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int co = blockIdx.x * 32 + c;
-  float s = 0.f;
-  if (co < Co)
-    for (int p = pl; p < parts; p += 8) s += part[(int64_t)p * Co + co];
-  red[pl][c] = s;
-  __syncthreads();
-  if (pl == 0 && co < Co) {
-    float t = 0.f;
-#pragma unroll
-    for (int l = 0; l < 8; ++l) t += red[l][c];
-    dbias[co] = t;
-  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -934,14 +916,6 @@ int vqa_pconv_dgrad(const void* dpooled, const uint8_t* argmax, const void* wd_i
 }
 
 static int pw_roles(int Ci, int Co) { return (Ci / 64) * (Co / 128); }
-// chunks per (image, 16-channel block) plane of the bias-gradient partial sums
-static int pw_bias_cpp(int B, int Co, int plane) {
-  int cpp = 2048 / (B * (Co / 16));
-  const int most = (plane + 127) / 128;
-  if (cpp > most) cpp = most;
-  return cpp < 1 ? 1 : cpp;
-}
-
 int vqa_pconv_wgrad_supported(int H, int W, int Ci, int Co) {
   if (H < 4 || W < 4 || Ci <= 0 || Co <= 0 || Ci % 64 || Co % 128) return 0;
   const int r = pw_roles(Ci, Co);
@@ -952,8 +926,7 @@ int vqa_pconv_wgrad_supported(int H, int W, int Ci, int Co) {
 
 int64_t vqa_pconv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co) {
   if (!vqa_pconv_wgrad_supported(H, W, Ci, Co) || B <= 0) return 0;
-  const int plane = ((H - 2) / 2) * ((W - 2) / 2);
-  return ((int64_t)256 * 9 * 64 * 128 + (int64_t)B * pw_bias_cpp(B, Co, plane) * Co) * 4;
+  return ((int64_t)256 * 9 * 64 * 128 + (int64_t)256 * 128) * 4;
 }
 
 int vqa_pconv_wgrad(const void* x, const void* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W,
@@ -972,6 +945,7 @@ int vqa_pconv_wgrad(const void* x, const void* dpooled, const uint8_t* argmax, f
   P.x = static_cast<const char*>(x); P.x_end = P.x + (int64_t)B * H * W * Ci * 2;
   P.dp = static_cast<const char*>(dpooled); P.am = reinterpret_cast<const char*>(argmax);
   P.slabs = workspace;
+  P.bslabs = workspace + (int64_t)256 * 9 * 64 * 128;
   P.B = B; P.H = H; P.W = W; P.Ci = Ci; P.Co = Co; P.Hp = Hp; P.Wp = Wp;
   P.tiles_y = (2 * Hp + 3) / 4; P.tiles_x = (2 * Wp + 31) / 32;
   P.ntiles = B * P.tiles_y * P.tiles_x;
@@ -989,18 +963,9 @@ int vqa_pconv_wgrad(const void* x, const void* dpooled, const uint8_t* argmax, f
   hipLaunchKernelGGL(pconv_wgrad_kernel, dim3(grid), dim3(512), PW_LDS, s, P);
   rc = check_hip(hipGetLastError(), "pconv_wgrad launch");
   if (rc) return rc;
-  hipLaunchKernelGGL(pconv_wgrad_reduce_kernel, dim3((9 * Ci * Co + 255) / 256), dim3(256), 0, s, workspace, dw, Ci, Co, grid,
-                     P.nroles, P.roles_co);
-  rc = check_hip(hipGetLastError(), "pconv_wgrad_reduce launch");
-  if (rc) return rc;
-  const int plane = Hp * Wp, cpp = pw_bias_cpp(B, Co, plane), per = (plane + cpp - 1) / cpp;
-  float* const bpart = workspace + (int64_t)256 * 9 * 64 * 128;
-  hipLaunchKernelGGL(pconv_bias_part_kernel, dim3(B * (Co / 16) * cpp), dim3(256), 0, s, static_cast<const uint16_t*>(dpooled),
-                     argmax, bpart, plane, Co, cpp, per);
-  rc = check_hip(hipGetLastError(), "pconv_bias_part launch");
-  if (rc) return rc;
-  hipLaunchKernelGGL(pconv_bias_reduce_kernel, dim3((Co + 31) / 32), dim3(256), 0, s, bpart, dbias, B * cpp, Co);
-  return check_hip(hipGetLastError(), "pconv_bias_reduce launch");
+  hipLaunchKernelGGL(pconv_wgrad_reduce_kernel, dim3((9 * Ci * Co + Co + 255) / 256), dim3(256), 0, s, workspace, P.bslabs, dw, dbias,
+                     Ci, Co, grid, P.nroles, P.roles_co);
+  return check_hip(hipGetLastError(), "pconv_wgrad_reduce launch");
 }
 
 }  // extern "C"

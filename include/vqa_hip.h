@@ -353,7 +353,8 @@ int vqa_pconv_dgrad(const void* dpooled, const uint8_t* argmax, const void* wd_i
 /* weight + bias gradient: dw [Co][Ci][3][3], dbias [Co] fp32.  A workgroup holds a whole [9 taps x 64 ci] x [128 co] block of
  * dW in its accumulators and streams 4 x 32-pixel tiles of x (C16; LDS patch, nine shifted transpose-reads) and of the routed
  * pre-pool gradient through LDS; one fp32 slab per workgroup, summed by a reduce kernel (deterministic).  Ci % 64 == 0,
- * Co % 128 == 0, and (Ci / 64) * (Co / 128) in {1, 2, 4, 8}; dbias is the masked sum of dpooled (arg-max != 4). */
+ * Co % 128 == 0, and (Ci / 64) * (Co / 128) in {1, 2, 4, 8}; dbias is the masked sum of dpooled (arg-max != 4), summed by the
+ * same kernel as the pieces of dpooled pass through it. */
 int vqa_pconv_wgrad_supported(int H, int W, int Ci, int Co);
 int64_t vqa_pconv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co);
 int vqa_pconv_wgrad(const void* x, const void* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W,

@@ -456,10 +456,27 @@ __global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int w
     if (mode != 0) qv = reinterpret_cast<const float4*>(qp + (int64_t)b * mid)[c];
     const float4 rq = make_float4(fmaxf(qv.x, 0.f), fmaxf(qv.y, 0.f), fmaxf(qv.z, 0.f), fmaxf(qv.w, 0.f));
     float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int pp = p0; pp < p1; ++pp) {
+    // rows in batches of four: the four loads of x (and the batch's dscore values) are issued before the first of them is
+    // used -- xs is rewritten in place, so hipcc may not move a row's load above the previous row's store by itself, and one
+    // dependent load -> compute -> store chain per row left the kernel at 4 TB/s
+    for (int pb = p0; pb < p1; pb += 4) {
+      float4 xb[4];
+      float dsb[4][G];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = pb + u < p1 ? pb + u : p1 - 1;
+        const int64_t m = (int64_t)b * P + pp;
+        xb[u] = ld4<XB>(static_cast<const char*>(xs) + m * mid * (XB ? 2 : 4), c);
+#pragma unroll
+        for (int g = 0; g < G; ++g) dsb[u][g] = dscore[((int64_t)b * G + g) * P + pp];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+      const int pp = pb + u;
+      if (pp >= p1) break;
       const int64_t m = (int64_t)b * P + pp;
       char* xrow = static_cast<char*>(xs) + m * mid * (XB ? 2 : 4);
-      const float4 x = ld4<XB>(xrow, c);
+      const float4 x = xb[u];
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
       if (p > 0.f) {
         const uint64_t e = (uint64_t)m * xld + 4 * c;
@@ -469,7 +486,7 @@ __global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int w
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        ds[g] = dscore[((int64_t)b * G + g) * P + pp];
+        ds[g] = dsb[u][g];
         t.x += ds[g] * w[g].x; t.y += ds[g] * w[g].y; t.z += ds[g] * w[g].z; t.w += ds[g] * w[g].w;
         dw[g].x += ds[g] * x.x * sc.x; dw[g].y += ds[g] * x.y * sc.y; dw[g].z += ds[g] * x.z * sc.z; dw[g].w += ds[g] * x.w * sc.w;
       }
@@ -498,6 +515,7 @@ __global__ void att_score_bwd_kernel(const float* dscore, const float* wx, int w
         dq.z += qv.z > 0.f ? t2.z * s2.z : 0.f; dq.w += qv.w > 0.f ? t2.w * s2.w : 0.f;
       }
       st4<XB>(xrow, c, d);
+      }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {

@@ -126,6 +126,70 @@ __global__ void l2norm_bwd_kernel(const float* dvn, const float* vn, const float
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int nch = C >> 2;
+  if (nch <= 64) {
+    // C <= 256 (every config of the reference): a lane holds its 4 channels of the row in registers -- one pass over memory
+    // instead of two -- and a wave has TWO rows in flight
+    const int c = lane;
+    const bool cok = c < nch;
+    for (int64_t r0 = 2 * wave; r0 < rows; r0 += 2 * nwaves) {
+      float4 a[2], b[2];
+      int64_t img[2], pos[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t r = r0 + u < rows ? r0 + u : rows - 1;
+        img[u] = G > 0 || OB == 2 ? r / positions : 0;
+        pos[u] = r - img[u] * positions;
+        b[u] = cok ? reinterpret_cast<const float4*>(vn + r * C)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (G == 0) {
+          a[u] = cok ? reinterpret_cast<const float4*>(dvn + r * C)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (cok) {
+#pragma unroll
+            for (int q = 0; q < (G > 0 ? G : 1); ++q) {
+              const float pr = probs[(img[u] * G + q) * positions + pos[u]];
+              const float4 go = reinterpret_cast<const float4*>(dout + img[u] * dout_ld + (int64_t)q * C)[c];
+              o.x += pr * go.x; o.y += pr * go.y; o.z += pr * go.z; o.w += pr * go.w;
+            }
+            x = reinterpret_cast<const float4*>(dv_in + r * C)[c];
+            if (p_v > 0.f) {
+              const float4 ds_ = drop_scale4(seed_v, (uint64_t)r * C + 4 * c, p_v, inv_keep_v);
+              x.x *= ds_.x; x.y *= ds_.y; x.z *= ds_.z; x.w *= ds_.w;
+            }
+          }
+          a[u] = make_float4(o.x + x.x, o.y + x.y, o.z + x.z, o.w + x.w);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t r = r0 + u;
+        float dot = a[u].x * b[u].x + a[u].y * b[u].y + a[u].z * b[u].z + a[u].w * b[u].w;
+        dot = wave_sum(dot);
+        if (r >= rows) break;
+        const float n = norm[r];
+        const float inv = 1.0f / (n + 1e-12f);
+        const float k = n > 0.f ? dot * (n + 1e-12f) / n : 0.f;
+        if (!cok) continue;
+        float4 d = make_float4((a[u].x - b[u].x * k) * inv, (a[u].y - b[u].y * k) * inv, (a[u].z - b[u].z * k) * inv,
+                               (a[u].w - b[u].w * k) * inv);
+        if (p > 0.f) {
+          const float4 ds_ = drop_scale4(seed, (uint64_t)r * C + 4 * c, p, inv_keep);
+          d.x *= ds_.x; d.y *= ds_.y; d.z *= ds_.z; d.w *= ds_.w;
+        }
+        if (OB) {
+          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+          const bf2 lo = {(__bf16)d.x, (__bf16)d.y}, hi = {(__bf16)d.z, (__bf16)d.w};
+          const uint2 o = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+          if (OB == 2) *reinterpret_cast<uint2*>(dpooled16 + ((img[u] * (C >> 4) + (c >> 2)) * positions + pos[u]) * 16 + (c & 3) * 4) = o;
+          else reinterpret_cast<uint2*>(dpooled16 + r * C)[c] = o;
+        } else {
+          reinterpret_cast<float4*>(dpooled + r * C)[c] = d;
+        }
+      }
+    }
+    return;
+  }
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float4* g = reinterpret_cast<const float4*>(dvn + r * C);
     const float4* v = reinterpret_cast<const float4*>(vn + r * C);

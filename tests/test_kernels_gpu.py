@@ -224,14 +224,15 @@ def test_nchw_to_nhwc4():
 
 
 # ----------------------------------------------------------------------------- point-wise / reductions
-def test_l2norm_fwd_bwd():
+@pytest.mark.parametrize("C", [32, 256, 288])        # <= 256: the one-pass register form; above: the two-pass loop
+def test_l2norm_fwd_bwd(C):
     ops = _ops()
     g = torch.Generator().manual_seed(3)
-    u = torch.randn(37, 32, generator=g)
+    u = torch.randn(37, C, generator=g)
     u[5] = 0.0   # an all-zero pixel: norm 0 -> vn 0, finite gradient
     ur = u.double().requires_grad_(True)
     vr = ur / (ur.norm(p=2, dim=1, keepdim=True).expand_as(ur) + 1e-12)
-    dv = torch.randn(37, 32, generator=g)
+    dv = torch.randn(37, C, generator=g)
     vr.backward(dv.double())
     vn, norm = ops.l2norm_fwd(u.to(DEV), 0.0, 0)
     du = ops.l2norm_bwd(dv.to(DEV), vn, norm, 0.0, 0)
@@ -263,7 +264,8 @@ def test_l2norm_second_output_and_dropout_add():
     assert float((acc - want).abs().max()) <= 1e-6 * float(want.abs().max())      # fused multiply-add vs two roundings
 
 
-@pytest.mark.parametrize("B,Hp,Wp,C,G,p_v,p", [(3, 5, 7, 64, 2, 0.3, 0.2), (2, 4, 4, 256, 1, 0.0, 0.0), (5, 3, 9, 128, 4, 0.5, 0.0)])
+@pytest.mark.parametrize("B,Hp,Wp,C,G,p_v,p", [(3, 5, 7, 64, 2, 0.3, 0.2), (2, 4, 4, 256, 1, 0.0, 0.0), (5, 3, 9, 128, 4, 0.5, 0.0),
+                                              (2, 3, 3, 512, 2, 0.3, 0.1), (1, 7, 5, 320, 3, 0.0, 0.4)])
 def test_l2norm_bwd_joined_equals_the_three_kernel_form(B, Hp, Wp, C, G, p_v, p):
     """vqa_l2norm_bwd_joined (d loss / d vn joined in the kernel from probs x dcomb and dropout-mask x dv_in) against
     att_apply_bwd -> dropout_add -> l2norm_bwd through the [B*P][C] tensor: fp32, bf16 and channel-blocked bf16 outputs."""

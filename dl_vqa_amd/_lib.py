@@ -71,7 +71,8 @@ PROTOTYPES = {
     "vqa_l2norm_bwd": (i32, [f32p, f32p, f32p, vp, i32, i64, i32, i32, f32, u64, vp]),
     "vqa_l2norm_bwd_joined": (i32, [f32p, i64, f32p, i32, f32p, f32, u64, f32p, f32p, vp, i32, i64, i32, i32, f32, u64, vp]),
     "vqa_embed_tanh_fwd": (i32, [i64p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp, vp]),
-    "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp]),
+    "vqa_embed_tanh_bwd_workspace_bytes": (i64, [i32, i32, i32]),
+    "vqa_embed_tanh_bwd": (i32, [i64p, f32p, f32p, f32p, i32, i32, i32, i32, f32, u64, vp, i64, vp]),
     "vqa_lstm_cell_fwd": (i32, [f32p, f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, f32p, i64, i32, i32, vp]),
     "vqa_lstm_cell_bwd": (i32, [f32p, f32p, f32p, i64p, i32, f32p, f32p, f32p, i32, i32, vp]),
     "vqa_lstm_step_supported": (i32, [i32]),

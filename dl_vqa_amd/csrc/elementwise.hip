@@ -320,6 +320,124 @@ __global__ __launch_bounds__(256) void embed_tanh_bwd_kernel(const int64_t* q, c
   }
 }
 
+// The same result from a slot INDEX: the kernel above scans all B*T slots once per vocabulary row -- O(V * B*T)
+// whatever the number of rows that are hit (hundreds of millions of reads at a real vocabulary with the stress shape).  With a
+// workspace the slots are first binned by token (integer atomics: the bin CONTENTS are deterministic, their order is not), and a
+// row's workgroup sorts its own bin ascending before it sums, so the summation order -- ascending slot index -- and therefore
+// every bit of demb equal the scanning kernel's.  Bins above 1 024 slots (a token in more than 1 024 slots of one batch) fall
+// back to the scan for that row only.
+__global__ void embed_hist_kernel(const int64_t* q, int N, int V, int* counts) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const int64_t tok = q[s];
+  if (tok > 0 && tok < V) atomicAdd(&counts[tok], 1);          // row 0 = padding index: no gradient
+}
+// offsets[v] = sum of counts[0..v), offsets[V] = total; cursor = a second copy for the fill pass.  One block of 1024 threads.
+__global__ __launch_bounds__(1024) void embed_scan_kernel(const int* counts, int* offsets, int* cursor, int V) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int v0 = 0; v0 < V; v0 += 1024) {
+    const int v = v0 + threadIdx.x;
+    const int cnt = v < V ? counts[v] : 0;
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                        // inclusive Hillis-Steele scan of the chunk
+      const int add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const int excl = carry + part[threadIdx.x] - cnt;
+    if (v < V) { offsets[v] = excl; cursor[v] = excl; }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[V] = carry;
+}
+__global__ void embed_fill_kernel(const int64_t* q, int N, int V, int* cursor, int* slots) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= N) return;
+  const int64_t tok = q[s];
+  if (tok > 0 && tok < V) slots[atomicAdd(&cursor[tok], 1)] = s;
+}
+constexpr int EMB_BIN_CAP = 1024;
+__global__ __launch_bounds__(256) void embed_tanh_bwd_binned_kernel(const int64_t* q, const float* x, const float* dx, float* demb,
+                                                                    int B, int T, int E, int V, float p, float inv_keep,
+                                                                    uint64_t seed, const int* offsets, const int* slots) {
+  __shared__ int bin[EMB_BIN_CAP];
+  __shared__ int hits[256];
+  __shared__ int wcount[4];
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = B * T;
+  const int o0 = offsets[v], n = offsets[v + 1] - o0;
+  if (n == 0) {                                                  // rows nothing references (and row 0): zeros
+    for (int e = tid; e < E; e += 256) demb[(int64_t)v * E + e] = 0.f;
+    return;
+  }
+  const bool binned = n <= EMB_BIN_CAP;
+  if (binned) {
+    int np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) bin[i] = i < n ? slots[o0 + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)                           // bitonic sort, ascending
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < np2; i += 256) {
+          const int l = i ^ j;
+          if (l > i) {
+            const int a = bin[i], bb = bin[l];
+            const bool up = (i & k) == 0;
+            if ((a > bb) == up) { bin[i] = bb; bin[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+  }
+  for (int e0 = 0; e0 < E; e0 += 1024) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    auto add_slot = [&](int sl) {
+      const int b = sl / T, t = sl - b * T;
+      const int64_t row = ((int64_t)t * B + b) * E;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + tid + 256 * k;
+        if (e < E) {
+          const float xv = x[row + e];
+          float g = dx[row + e] * (1.f - xv * xv);
+          if (p > 0.f) g *= drop_scale(seed, ((uint64_t)b * T + t) * E + e, p, inv_keep);
+          acc[k] += g;
+        }
+      }
+    };
+    if (binned) {
+      for (int h = 0; h < n; ++h) add_slot(bin[h]);
+    } else {                                                     // an over-full bin: this row scans, as the kernel above
+      for (int s0 = 0; s0 < N; s0 += 256) {
+        const int s = s0 + tid;
+        const bool hit = s < N && q[s] == (int64_t)v;
+        const int total = __syncthreads_count(hit);
+        if (total == 0) continue;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wcount[w];
+        if (hit) hits[base + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+        __syncthreads();
+        for (int h = 0; h < total; ++h) add_slot(hits[h]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = e0 + tid + 256 * k;
+      if (e < E) demb[(int64_t)v * E + e] = acc[k];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ LSTM cell
 __global__ void lstm_cell_fwd_kernel(const float* xg, const float* hg, const float* c_in, const float* h_in,
                                      const int64_t* q_len, int t, float* gates, float* c_out, float* h_out,
@@ -1062,11 +1180,36 @@ int vqa_embed_tanh_fwd(const int64_t* q, const float* emb, float* x, int B, int 
   return check_hip(hipGetLastError(), "embed_tanh_fwd launch");
 }
 
+int64_t vqa_embed_tanh_bwd_workspace_bytes(int B, int T, int V) {
+  if (B <= 0 || T <= 0 || V <= 0) return 0;
+  return ((int64_t)3 * V + 2 + (int64_t)B * T) * 4;             // counts[V] offsets[V+1] cursor[V] slots[B*T] (int32)
+}
+
 int vqa_embed_tanh_bwd(const int64_t* q, const float* x, const float* dx, float* demb, int B, int T, int E, int V,
-                       float p, uint64_t seed, vqa_stream_t stream) {
+                       float p, uint64_t seed, void* workspace, int64_t workspace_bytes, vqa_stream_t stream) {
   VQA_REQUIRE(q && x && dx && demb && B > 0 && T > 0 && E > 0 && V > 0, "vqa_embed_tanh_bwd: bad args");
-  hipLaunchKernelGGL(embed_tanh_bwd_kernel, dim3(V), dim3(256), 0, STREAM, q, x, dx, demb, B, T, E, V, p, KEEP(p), seed);
-  return check_hip(hipGetLastError(), "embed_tanh_bwd launch");
+  if (!workspace) {                                              // no workspace: the scanning kernel, O(V * B*T)
+    hipLaunchKernelGGL(embed_tanh_bwd_kernel, dim3(V), dim3(256), 0, STREAM, q, x, dx, demb, B, T, E, V, p, KEEP(p), seed);
+    return check_hip(hipGetLastError(), "embed_tanh_bwd launch");
+  }
+  if (workspace_bytes < vqa_embed_tanh_bwd_workspace_bytes(B, T, V)) {
+    set_error("vqa_embed_tanh_bwd: workspace %lld < %lld", (long long)workspace_bytes,
+              (long long)vqa_embed_tanh_bwd_workspace_bytes(B, T, V));
+    return VQA_ERR_WORKSPACE;
+  }
+  const int N = B * T;
+  int* const counts = static_cast<int*>(workspace);
+  int* const offsets = counts + V;
+  int* const cursor = offsets + V + 1;
+  int* const slots = cursor + V;
+  int rc = check_hip(hipMemsetAsync(counts, 0, (size_t)V * 4, STREAM), "embed_tanh_bwd memset");
+  if (rc) return rc;
+  hipLaunchKernelGGL(embed_hist_kernel, dim3((N + 255) / 256), dim3(256), 0, STREAM, q, N, V, counts);
+  hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, STREAM, counts, offsets, cursor, V);
+  hipLaunchKernelGGL(embed_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, STREAM, q, N, V, cursor, slots);
+  hipLaunchKernelGGL(embed_tanh_bwd_binned_kernel, dim3(V), dim3(256), 0, STREAM, q, x, dx, demb, B, T, E, V, p, KEEP(p), seed,
+                     offsets, slots);
+  return check_hip(hipGetLastError(), "embed_tanh_bwd(binned) launch");
 }
 
 int vqa_lstm_cell_fwd(const float* xg, const float* hg, const float* c_in, const float* h_in, const int64_t* q_len,

@@ -285,10 +285,15 @@ def embed_tanh_fwd(q: torch.Tensor, emb: torch.Tensor, p: float, seed: int,
     return x
 
 
-def embed_tanh_bwd(q, x, dx, demb, p: float, seed: int):
+def embed_tanh_bwd(q, x, dx, demb, p: float, seed: int, binned: bool = True):
+    """binned=False: the workspace-less scanning kernel (O(V * B*T)); same bits."""
     B, T = q.shape
     V, E = demb.shape
-    call("vqa_embed_tanh_bwd", ptr(q), ptr(x), ptr(dx), ptr(demb), B, T, E, V, p, seed, stream())
+    if binned:
+        ws = workspace(_lib.load().vqa_embed_tanh_bwd_workspace_bytes(B, T, V), q.device)
+        call("vqa_embed_tanh_bwd", ptr(q), ptr(x), ptr(dx), ptr(demb), B, T, E, V, p, seed, ptr(ws), ws.numel() * 4, stream())
+    else:
+        call("vqa_embed_tanh_bwd", ptr(q), ptr(x), ptr(dx), ptr(demb), B, T, E, V, p, seed, None, 0, stream())
 
 
 def lstm_cell_fwd(xg_t, hg, c_in, h_in, q_len, t, gates, c_out, h_out, c_final=None, cf_ld=0):

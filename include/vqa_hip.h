@@ -28,7 +28,7 @@ extern "C" {
 
 /* Bumped whenever an exported entry point changes its argument list or disappears (round 1: 1, round 2: 2, round 3: 3).
  * dl_vqa_amd/_lib.py parses this line and refuses a library that answers differently. */
-#define VQA_ABI_VERSION 4
+#define VQA_ABI_VERSION 5
 
 #define VQA_OK 0
 #define VQA_ERR_INVALID 1 /* bad argument (shape, alignment, null pointer) */
@@ -173,8 +173,12 @@ int vqa_embed_tanh_fwd(const int64_t* q, const float* emb, float* x, int B, int 
                        float p, uint64_t seed, int32_t* bad_tokens, vqa_stream_t stream);
 /* demb[v][:] = sum over the slots (b,t) with q[b][t] == v of dx * (1 - x^2) * dropmask, in slot order
  * (deterministic, no atomics); every row of demb [V][E] is WRITTEN (row 0 = padding_idx and unused rows: zeros). */
+/* workspace (optional, vqa_embed_tanh_bwd_workspace_bytes): the slots are binned by token first and every row sums its own
+ * (sorted) bin -- O(B*T + V) instead of the workspace-less form's scan of all B*T slots per vocabulary row; same bits. */
+int64_t vqa_embed_tanh_bwd_workspace_bytes(int B, int T, int V);
 int vqa_embed_tanh_bwd(const int64_t* q, const float* x, const float* dx, float* demb, int B, int T,
-                       int E, int V, float p, uint64_t seed, vqa_stream_t stream);
+                       int E, int V, float p, uint64_t seed, void* workspace /* may be NULL */, int64_t workspace_bytes,
+                       vqa_stream_t stream);
 /* One LSTM time step for one direction (gate order i,f,g,o; nn.LSTM, model.py:145-149):
  *   pre = xg[b] + hg[b]   (xg = x W_ih^T + b_ih + b_hh for time t, hg = h_in W_hh^T, both [B][4H])
  *   rows with t >= q_len[b] keep (h,c) unchanged — the packed-sequence semantics of model.py:159-164.

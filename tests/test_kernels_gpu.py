@@ -320,6 +320,29 @@ def test_embed_tanh_fwd_bwd():
     assert float(demb[0].abs().max()) == 0.0 and int(bad) == 0
 
 
+@pytest.mark.parametrize("V,E,B,T,hot", [(5000, 300, 64, 14, 0), (40, 64, 300, 9, 0), (3000, 96, 700, 6, 1500), (7, 1100, 50, 5, 0)])
+def test_embed_bwd_binned_equals_the_scanning_kernel(V, E, B, T, hot):
+    """ADVICE r2: with a workspace the slots are binned by token and every vocabulary row sums its own sorted bin (O(B*T + V));
+    without one every row scans all B*T slots.  Same summation order, so the same bits -- incl. a token in more than 1 024 slots
+    (bin overflow: that row scans), a vocabulary much larger than the batch, bad ids, train-mode dropout."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(V + B)
+    emb = torch.randn(V, E, generator=g)
+    q = torch.randint(0, V, (B, T), generator=g)
+    if hot:
+        q.view(-1)[torch.randperm(B * T, generator=g)[:hot]] = 3
+    q[1, 2], q[2, 0] = V + 1, -4
+    dx = torch.randn(T, B, E, generator=g).to(DEV)
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    x = ops.embed_tanh_fwd(q.to(DEV), emb.to(DEV), 0.3, 99, bad)
+    d1 = torch.full((V, E), 7.0, device=DEV)
+    d2 = torch.full((V, E), -7.0, device=DEV)
+    ops.embed_tanh_bwd(q.to(DEV), x, dx, d1, 0.3, 99, binned=True)
+    ops.embed_tanh_bwd(q.to(DEV), x, dx, d2, 0.3, 99, binned=False)
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d2) and float(d1[0].abs().max()) == 0.0 and bool(torch.isfinite(d1).all())
+
+
 def test_embed_bwd_is_deterministic_and_counts_bad_tokens():
     """Many slots per vocabulary row (B*T >> V, more than one 256-slot scan round, > 256 hits of one token in a
     round impossible by construction): the per-row sums run in slot order, so two launches agree bit for bit;

@@ -112,6 +112,49 @@ __global__ __launch_bounds__(256, 4) void conv0_fwd_kernel(const void* __restric
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s][j], s == 0 ? zero : acc[j], 0, 0, 0);
     }
     const bool inner = 8 * t + 8 <= nwin;                       // uniform
+    if (OB == 0) {
+      // fp32 output (the headline path): the tile's 8 windows x Co channels go through a wave-private LDS scratch behind the
+      // patch -- pooled [window][Co] fp32, arg-max [window][Co] bytes, both contiguous in NHWC -- and leave as 16-byte-per-lane
+      // stores: 2 TN + 1 instead of 8 TN four-byte and 8 TN one-byte store instructions per tile (store-issue bound, as the
+      // bf16 kernels were)
+      char* const scr = reinterpret_cast<char*>(patch) + CI * C0_PR * RS * 4 + wave * (8 * Co * 5);
+      char* const sam = scr + 8 * Co * 4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float best = acc[j][4 * g];
+          int a = 0;
+          if (acc[j][4 * g + 1] > best) { best = acc[j][4 * g + 1]; a = 1; }
+          if (acc[j][4 * g + 2] > best) { best = acc[j][4 * g + 2]; a = 2; }
+          if (acc[j][4 * g + 3] > best) { best = acc[j][4 * g + 3]; a = 3; }
+          best += bv[j];
+          const int win = 2 * g + h;
+          *reinterpret_cast<float*>(scr + (win * Co + 32 * j + l31) * 4) = best > 0.f ? best : 0.f;
+          *reinterpret_cast<uint8_t*>(sam + win * Co + 32 * j + l31) = best > 0.f ? (uint8_t)a : (uint8_t)4;
+        }
+      }
+      asm volatile("" ::: "memory");        // the wave's LDS accesses execute in order; keep the compiler's order as well
+#pragma unroll
+      for (int q = 0; q < TN; ++q) {         // pooled: 8 * Co * 4 bytes = TN KiB
+        const int byte = q * 1024 + lane * 16;
+        const int win = byte / (Co * 4);
+        const float4 v = *reinterpret_cast<const float4*>(scr + byte);
+        const bool ok = inner || 8 * t + win < nwin;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, ok ? (int)(8 * t * Co * 4 + byte) : (int)BUF_OOB, 0, 0);
+      }
+      {
+        const int byte = lane * 16;
+        if (byte < 8 * Co) {                 // arg-max: 8 windows x Co bytes
+          const int win = byte / Co;
+          const float4 v = *reinterpret_cast<const float4*>(sam + byte);
+          const bool ok = inner || 8 * t + win < nwin;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ra, ok ? (int)(8 * t * Co + byte) : (int)BUF_OOB, 0, 0);
+        }
+      }
+      asm volatile("" ::: "memory");
+      continue;
+    }
     const uint32_t vl = (uint32_t)__mul24(8 * t + h, Co) + (uint32_t)l31;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -545,6 +588,130 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const void* __restrict
     bias_slab[(int64_t)blockIdx.x * Co + e] = cb[e] + cb[Co + e] + cb[2 * Co + e] + cb[3 * Co + e];
 }
 
+// ------------------------------------------------------------------ wgrad, next row prefetched into registers (round 3)
+// The kernel above is load -> barrier -> compute -> barrier per pooled row; with three workgroups per CU the HBM round trip of a
+// row's operands still stood in front of its MFMAs.  Here the NEXT row's image rows, pooled gradient and arg-max bytes are loaded
+// into registers before the current row is computed and go to LDS after it (W <= 256, Wp * Co <= 8192; wider images take the
+// kernel above).  XH: the image is __half / float.
+template <int CI, int TN, bool XH>
+__global__ __launch_bounds__(256) void conv0_wgrad_pf_kernel(const void* __restrict__ x, const float* __restrict__ dp,
+                                                          const uint8_t* __restrict__ am, float* slab, float* bias_slab,
+                                                          int B, int H, int W, int Hp, int Wp, int RS, int PLANE) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int K = 9 * CI, Co = 32 * TN;
+  float* patch = lds;
+  float* dps = lds + ((CI * PLANE + 3) & ~3);
+  uint8_t* ams = reinterpret_cast<uint8_t*>(dps + Wp * Co);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  // lane l31 owns tap i = l31 of the 32-row A operand (rows >= K are don't-care: never written out)
+  const int i = l31 < K ? l31 : 0;
+  const int c = i / 9, t9 = i - 9 * c, ky = t9 / 3, kx = t9 - 3 * ky;
+  const float* ap = patch + c * PLANE + ky * RS + kx + h;   // + h: the pixel pair (dx = h) of one MFMA
+  f32x16 acc[TN];
+  float bsum[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bsum[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+  const int rows_total = B * Hp;
+  const int rowv = Wp * Co;   // floats in one pooled-gradient row
+  // prefetch registers: image = (channel: round, image row: wave, 4-pixel piece: lane), pooled gradient / arg-max = 16-byte /
+  // 4-byte pieces tid + 256 i
+  constexpr int DR = 8;
+  typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+  h16x4 xh_[XH ? CI : 1];
+  float4 xf_[XH ? 1 : CI];
+  float4 dr_[DR];
+  uint32_t ar_[DR];
+  const int W4 = W >> 2, npieces = rowv >> 2;
+  auto load_row = [&](int row) {
+    const int b = row / Hp, py = row - b * Hp;
+#pragma unroll
+    for (int cc = 0; cc < CI; ++cc) {
+      const int64_t e = ((int64_t)(b * CI + cc) * H + 2 * py + wave) * W + 4 * lane;
+      const bool ok = lane < W4;
+      if (XH) xh_[cc] = ok ? *reinterpret_cast<const h16x4*>(static_cast<const uint16_t*>(x) + e) : h16x4{0, 0, 0, 0};
+      else xf_[cc] = ok ? *reinterpret_cast<const float4*>(static_cast<const float*>(x) + e) : f4zero();
+    }
+    const float* dprow = dp + (int64_t)row * rowv;
+    const uint8_t* amrow = am + (int64_t)row * rowv;
+#pragma unroll
+    for (int i = 0; i < DR; ++i) {
+      const int e = tid + 256 * i;
+      const bool in = e < npieces;
+      dr_[i] = in ? reinterpret_cast<const float4*>(dprow)[e] : f4zero();
+      ar_[i] = in ? reinterpret_cast<const uint32_t*>(amrow)[e] : 0u;
+    }
+  };
+  auto store_row = [&]() {
+    if (lane < W4) {
+#pragma unroll
+      for (int cc = 0; cc < CI; ++cc) {
+        float4 v;
+        if (XH) v = make_float4((float)xh_[cc][0], (float)xh_[cc][1], (float)xh_[cc][2], (float)xh_[cc][3]);
+        else v = xf_[cc];
+        float* d = patch + cc * PLANE + wave * RS + 4 * lane;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DR; ++i) {
+      const int e = tid + 256 * i;
+      if (e < npieces) {
+        reinterpret_cast<float4*>(dps)[e] = dr_[i];
+        reinterpret_cast<uint32_t*>(ams)[e] = ar_[i];
+      }
+    }
+  };
+  int row = blockIdx.x;
+  if (row < rows_total) load_row(row);
+  for (; row < rows_total; row += gridDim.x) {
+    __syncthreads();   // previous row fully consumed
+    store_row();
+    __syncthreads();
+    if (row + (int)gridDim.x < rows_total) load_row(row + gridDim.x);     // in flight under this row's MFMAs
+    for (int px = wave; px < Wp; px += 4) {
+      float d[TN];
+      int id[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { d[j] = dps[px * Co + 32 * j + l31]; id[j] = ams[px * Co + 32 * j + l31]; }
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {          // pixel pair (dy = hs, dx = h)
+        const float a = ap[hs * RS + 2 * px];
+        const int jj = 2 * hs + h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float bvv = id[j] == jj ? d[j] : 0.f;
+          bsum[j] += bvv;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // combine the 4 waves of the workgroup through LDS, then ONE partial per workgroup
+  __syncthreads();
+  float* comb = lds;                               // [4][32][Co] floats, fits the staging area
+  float* cb = lds + 4 * 32 * Co;                   // [4][Co]
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+      comb[(wave * 32 + k) * Co + 32 * j + l31] = acc[j][r];
+    }
+    const float s = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+    if (h == 0) cb[wave * Co + 32 * j + l31] = s;
+  }
+  __syncthreads();
+  float* out = slab + (int64_t)blockIdx.x * 32 * Co;
+  for (int e = tid; e < 32 * Co; e += 256)
+    out[e] = comb[e] + comb[32 * Co + e] + comb[2 * 32 * Co + e] + comb[3 * 32 * Co + e];
+  for (int e = tid; e < Co; e += 256)
+    bias_slab[(int64_t)blockIdx.x * Co + e] = cb[e] + cb[Co + e] + cb[2 * Co + e] + cb[3 * Co + e];
+}
+
 // ------------------------------------------------------------------ wgrad on bf16 MFMA (bf16 path, configs[3])
 // dW[tap][co] = sum over conv-output pixels of x(pixel, tap) * dY(pixel, co): the reduction index (pixels) is the MFMA k.
 //   A (rows = the 27 taps, k = 8 consecutive pixels of a conv row): the image rows are staged as bf16 in THREE copies
@@ -727,7 +894,7 @@ static bool c0_supported(int Ci, int H, int W, int Co, int stride) {
   // wgrad maps the 9*Ci taps onto the 32 rows of one MFMA A operand: Ci <= 3
   if (!(Ci >= 1 && Ci <= 3 && stride == 1 && (Co == 32 || Co == 64) && W % 4 == 0 && H >= 6 && Hp > 0 && Wp > 0))
     return false;
-  const size_t fwd = (size_t)Ci * C0_PR * c0_round_stride(W, 16) * 4;
+  const size_t fwd = (size_t)Ci * C0_PR * c0_round_stride(W, 16) * 4 + (size_t)4 * 8 * Co * 5;
   const int rs = c0_round_stride(W, 11);
   int plane = 4 * rs;
   while (plane % 32 != 3) ++plane;
@@ -770,9 +937,10 @@ int vqa_conv0_relu_pool_fwd(const void* x_nchw, int x_is_fp16, const float* w, c
 #define C0_FWD_LAUNCH(OB)                                                                                              \
   C0_DISPATCH(Ci, Co / 32, {                                                                                           \
     auto kern = conv0_fwd_kernel<kCI, kTN, OB>;                                                                        \
-    int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_fwd)");                       \
+    const size_t ldsk = lds + ((OB) == 0 ? (size_t)4 * 8 * Co * 5 : 0);   /* fp32 output: + the waves' store scratch */    \
+    int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)ldsk, "attr(conv0_fwd)");                      \
     if (rc0) return rc0;                                                                                               \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, x_nchw, xh, w, bias, pooled, argmax, H, W, Hp, Wp, RS); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), ldsk, (hipStream_t)stream, x_nchw, xh, w, bias, pooled, argmax, H, W, Hp, Wp, RS); \
   })
   if (pooled_is_bf16 == 2 || pooled_is_bf16 == 4) {      // bf16 MFMA (image and weights rounded to bf16), bf16 output (4: C16)
     VQA_REQUIRE(Ci <= 3, "vqa_conv0_relu_pool_fwd: the bf16-MFMA first block needs Ci <= 3");
@@ -840,12 +1008,25 @@ int vqa_conv0_wgrad(const void* x_nchw, int x_is_fp16, const float* dpooled, con
   float* slab = workspace;
   float* bias_slab = workspace + (int64_t)kC0Blocks * 32 * Co;
   hipStream_t s = (hipStream_t)stream;
+  const bool prefetch = W <= 256 && Wp * Co <= 8192;     // the register-prefetching form (conv0_wgrad_pf_kernel)
   C0_DISPATCH(Ci, Co / 32, {
-    auto kern = conv0_wgrad_kernel<kCI, kTN>;
-    int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad)");
-    if (rc0) return rc0;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, x_is_fp16 ? 1 : 0, dpooled, argmax, slab, bias_slab, B, H, W,
-                       Hp, Wp, RS, PLANE);
+    if (prefetch && x_is_fp16) {
+      auto kern = conv0_wgrad_pf_kernel<kCI, kTN, true>;
+      int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad)");
+      if (rc0) return rc0;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, dpooled, argmax, slab, bias_slab, B, H, W, Hp, Wp, RS, PLANE);
+    } else if (prefetch) {
+      auto kern = conv0_wgrad_pf_kernel<kCI, kTN, false>;
+      int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad)");
+      if (rc0) return rc0;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, dpooled, argmax, slab, bias_slab, B, H, W, Hp, Wp, RS, PLANE);
+    } else {
+      auto kern = conv0_wgrad_kernel<kCI, kTN>;
+      int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), (int)lds, "attr(conv0_wgrad)");
+      if (rc0) return rc0;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, x_nchw, x_is_fp16 ? 1 : 0, dpooled, argmax, slab, bias_slab, B, H, W,
+                         Hp, Wp, RS, PLANE);
+    }
   });
   int rc = check_hip(hipGetLastError(), "conv0_wgrad launch");
   if (rc) return rc;

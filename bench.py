@@ -153,12 +153,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (not for measurements): VQA_BENCH_DEVICE=0 puts every rank on one GPU and VQA_BENCH_BACKEND=gloo takes the
+    # collective through the host, so that the world_size > 1 branches of this script can be exercised on a one-GPU box
+    dev_index = int(os.environ.get("VQA_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("VQA_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from dl_vqa_amd import VqaNet, _lib
     from dl_vqa_amd.distributed import DataParallel

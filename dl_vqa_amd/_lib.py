@@ -107,6 +107,10 @@ PROTOTYPES = {
     "vqa_conv3x3_dgrad_bf16": (i32, [vp, u8p, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_conv3x3_wgrad_bf16_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "vqa_conv3x3_wgrad_bf16": (i32, [vp, vp, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32, f32p, i64, i32, vp]),
+    "vqa_pconvf_supported": (i32, [i32, i32, i32, i32, i32]),
+    "vqa_pconvf_weights_bytes": (i64, [i32, i32]),
+    "vqa_pconvf_pack_weights": (i32, [f32p, f32p, i32, i32, vp]),
+    "vqa_pconvf_dgrad": (i32, [f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_pconv_supported": (i32, [i32, i32, i32, i32, i32]),
     "vqa_pconv_weights_bytes": (i64, [i32, i32]),
     "vqa_pconv_pack_weights": (i32, [f32p, vp, vp, i32, i32, vp]),

@@ -291,8 +291,18 @@ class Engine:
                 wds.append(wdT)
                 continue
             x_shape = ops.nhwc_shape(acts[-1])
-            wf, wd = ops.conv_pack_weights(w, x_shape[3], need_wd=(keep and l > 0))
             x3 = self._x3_layer(x_shape, w.shape[0])
+            # fp32 backward-data of blocks 1.. on the patch kernel (csrc/conv_patch_f32.hip: the pre-pool gradient built in LDS once
+            # per K-slice instead of routed once per tap by the loaders); VQA_PDGRAD=0 keeps the implicit-GEMM kernel
+            # (measured at B = 256, 224 x 224: 64-channel input 3.96 -> 3.69 ms; 128-channel input 3.20 -> 3.32 ms, so blocks whose
+            # input has a multiple of 128 channels stay on the implicit-GEMM kernel unless VQA_PDGRAD=2 forces the patch kernel)
+            pdg_mode = os.environ.get("VQA_PDGRAD", "1")
+            pdg = (keep and l > 0 and not x3 and self.stride == 1 and acts[-1].dim() == 4 and pdg_mode != "0"
+                   and (x_shape[3] % 128 != 0 or pdg_mode == "2")
+                   and ops.pconvf_supported(x_shape[1], x_shape[2], x_shape[3], w.shape[0]))
+            wf, wd = ops.conv_pack_weights(w, x_shape[3], need_wd=(keep and l > 0 and not pdg))
+            if pdg:
+                wd = ("pconvf", ops.pconvf_pack_weights(w))
             if x3:
                 # operands are split once per tensor, not by every workgroup in every K-step: the weights here, the
                 # input activation by its producer (or here, when the producer could not: it replaces the fp32 tensor)
@@ -627,7 +637,9 @@ class Engine:
             dPp = ops.x3_pack_pooled_grad(dP, ctx.idxs[l], Gr[f"image.conv{l}.bias"]) if x3 else None
             ops.conv_wgrad(ctx.acts[l], dP, ctx.idxs[l], Gr[f"image.conv{l}.weight"],
                            None if x3 else Gr[f"image.conv{l}.bias"], self.stride, tag=l, x3=x3, dpooled_packed=dPp)
-            if l > 0:
+            if l > 0 and isinstance(ctx.wds[l], tuple):
+                dP = ops.pconvf_dgrad(dP, ctx.idxs[l], ctx.wds[l][1], x_shape, tag=l)
+            elif l > 0:
                 dP = ops.conv_dgrad(dPp if x3 else dP, ctx.idxs[l], ctx.wds[l], x_shape, self.stride, tag=l, x3=x3)
         ready("image")
         main.wait_event(ev0)

@@ -548,6 +548,30 @@ def conv_wgrad_bf16(x, dpooled, amax, dw: torch.Tensor, dbias: torch.Tensor, str
          ptr(ws), ws.numel() * 4, tag, stream())
 
 
+# ------------------------------------------------------------------ fp32 patch backward-data (csrc/conv_patch_f32.hip)
+def pconvf_supported(H: int, W: int, Ci: int, Co: int, stride: int = 1) -> bool:
+    return bool(_lib.load().vqa_pconvf_supported(H, W, Ci, Co, stride))
+
+
+def pconvf_pack_weights(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [Co,Ci,3,3] -> the flipped, transposed, fragment-ordered fp32 image pconvf_dgrad reads."""
+    Co, Ci = w.shape[0], w.shape[1]
+    wd = torch.empty(9 * Ci * Co, dtype=torch.float32, device=w.device)
+    call("vqa_pconvf_pack_weights", ptr(w), ptr(wd), Co, Ci, stream())
+    return wd
+
+
+def pconvf_dgrad(dpooled: torch.Tensor, amax: torch.Tensor, wd_img: torch.Tensor, x_shape, tag: int = 0, out=None) -> torch.Tensor:
+    """dpooled fp32 NHWC [B,Hp,Wp,Co] + arg-max bytes NHWC -> dX fp32 NHWC; x_shape = (B, H, W, Ci) of the block's input."""
+    B, H, W, Ci = x_shape
+    Co = dpooled.shape[3]
+    assert dpooled.dtype == torch.float32 and dpooled.is_contiguous() and amax.dtype == torch.uint8 and amax.is_contiguous()
+    assert tuple(dpooled.shape[1:3]) == conv_out_hw(H, W, 1) and amax.shape == dpooled.shape
+    dx = out if out is not None else torch.empty(B, H, W, Ci, dtype=torch.float32, device=dpooled.device)
+    call("vqa_pconvf_dgrad", ptr(dpooled), ptr(amax), ptr(wd_img), ptr(dx), B, H, W, Ci, Co, tag, stream())
+    return dx
+
+
 # ------------------------------------------------------------------ bf16 patch convolutions (csrc/conv_patch_bf16.hip)
 # Everything a patch is cut from lives in HBM channel-blocked, "C16" = [B][C/16][H][W][16] bf16 (a K-slice of a patch row is
 # one contiguous run); pooled fp32 outputs, dX, pooled gradients and arg-max bytes stay NHWC.

@@ -28,7 +28,7 @@ extern "C" {
 
 /* Bumped whenever an exported entry point changes its argument list or disappears (round 1: 1, round 2: 2, round 3: 3).
  * dl_vqa_amd/_lib.py parses this line and refuses a library that answers differently. */
-#define VQA_ABI_VERSION 5
+#define VQA_ABI_VERSION 6
 
 #define VQA_OK 0
 #define VQA_ERR_INVALID 1 /* bad argument (shape, alignment, null pointer) */
@@ -363,6 +363,18 @@ int vqa_pconv_wgrad_supported(int H, int W, int Ci, int Co);
 int64_t vqa_pconv_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co);
 int vqa_pconv_wgrad(const void* x, const void* dpooled, const uint8_t* argmax, float* dw, float* dbias, int B, int H, int W,
                     int Ci, int Co, float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
+
+/* fp32 patch backward-data (csrc/conv_patch_f32.hip; the autograd of models/model.py:80-82 on the fp32 headline path): the same
+ * dX as vqa_conv3x3_dgrad (stride 1) up to fp32 summation order, from the same operands (dpooled fp32 NHWC, argmax NHWC) --
+ * a persistent workgroup builds the pre-pool gradient of an 8-channel slice in LDS once (routed from dpooled + argmax) and
+ * takes the nine taps as shifted fragment reads over a FLATTENED segment of the padded map (no 2-D edge waste at 111- and
+ * 54-pixel maps), exact fp32 MFMA.  wd_img = vqa_pconvf_pack_weights(w) (flipped, transposed, fragment order),
+ * vqa_pconvf_weights_bytes.  Ci % 64 == 0, Co % 8 == 0, W <= 256 (vqa_pconvf_supported). */
+int vqa_pconvf_supported(int H, int W, int Ci, int Co, int stride);
+int64_t vqa_pconvf_weights_bytes(int Ci, int Co);
+int vqa_pconvf_pack_weights(const float* w /* [Co][Ci][3][3] */, float* wd_img, int Co, int Ci, vqa_stream_t stream);
+int vqa_pconvf_dgrad(const float* dpooled, const uint8_t* argmax, const float* wd_img, float* dx, int B, int H, int W, int Ci,
+                     int Co, int tag, vqa_stream_t stream);
 
 /* ---- fp32 on the bf16 matrix cores ("fp32x3": csrc/x3_core.hpp) -------------------------------
  * The same fp32 tensors, layouts and results contract as the fp32 entry points above; inside the K loop every

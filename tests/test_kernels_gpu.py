@@ -216,6 +216,41 @@ def test_conv_relu_pool_fwd_bwd(B, H, W, Ci, Co, stride):
     check("conv bias grad", db, br.grad, 2e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 30, 30, 64, 128), (3, 23, 41, 128, 256), (1, 111, 111, 64, 128), (5, 17, 9, 64, 8),
+                                         (2, 54, 54, 128, 256), (1, 12, 200, 64, 16)])
+def test_pconvf_dgrad_matches_the_implicit_gemm_kernel_and_float64(B, H, W, Ci, Co):
+    """csrc/conv_patch_f32.hip (flattened-segment patch kernel, exact fp32 MFMA): dX against float64 autograd and against
+    vqa_conv3x3_dgrad on the same operands -- odd sizes (dropped pool rows / columns, padded-width garbage columns), segments that
+    end inside an image, several images per workgroup stream, 64- and 128-channel outputs, wide and narrow maps."""
+    ops = _ops()
+    assert ops.pconvf_supported(H, W, Ci, Co)
+    g = torch.Generator().manual_seed(H * 7 + W + Ci)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)
+    b = torch.randn(Co, generator=g) * 0.1
+    xr, wr, br = x.double().requires_grad_(True), w.double(), b.double()
+    yr = F.max_pool2d(torch.relu(F.conv2d(xr, wr, br)), 2, 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wf, wd = ops.conv_pack_weights(w.to(DEV), Ci)
+    pooled, am = ops.conv_fwd(xd, wf, b.to(DEV), 1)
+    dp = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    want = ops.conv_dgrad(dp, am, wd, tuple(xd.shape), 1)
+    got = ops.pconvf_dgrad(dp, am, ops.pconvf_pack_weights(w.to(DEV)), tuple(xd.shape))
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-6 * math.sqrt(9 * Co) * scale
+    # float64 reference with the KERNEL's arg-max (a near-tie may pick another pixel of a window in float64)
+    Hp, Wp = yr.shape[2], yr.shape[3]
+    dyfull = torch.zeros(B, H - 2, W - 2, Co, dtype=torch.float64)
+    amc, dpc = am.cpu(), dp.cpu().double()
+    for j in range(4):
+        dyfull[:, (j >> 1):2 * Hp:2, (j & 1):2 * Wp:2, :] = torch.where(amc == j, dpc, torch.zeros_like(dpc))
+    dx_ref = torch.nn.grad.conv2d_input(xr.shape, wr, dyfull.permute(0, 3, 1, 2))
+    check(f"pconvf dgrad {B,H,W,Ci,Co}", got.permute(0, 3, 1, 2), dx_ref, 3e-6 * math.sqrt(9 * Co))
+
+
 def test_nchw_to_nhwc4():
     ops = _ops()
     x = torch.randn(2, 3, 9, 11)

@@ -109,7 +109,10 @@ def _w16(w: Tensor, on: bool) -> Tensor:
 
 def fc16_dims_ok(sd: Dict[str, Tensor]) -> bool:
     """bf16 path: q_lin / lin1 / lin2 run on bf16 MFMA when every one of their dimensions is a multiple of 8 (the bf16 GEMM's
-    16-byte operand rows); the same rule as dl_vqa_amd.engine.Engine.fc16."""
+    16-byte operand rows); the same rule as dl_vqa_amd.engine.Engine.fc16, including its A/B switch VQA_FC16=0 (fp32 FC layers)."""
+    import os
+    if os.environ.get("VQA_FC16", "1") == "0":
+        return False
     dims = list(sd["attention.q_lin.weight"].shape) + list(sd["classifier.lin1.weight"].shape) + \
         list(sd["classifier.lin2.weight"].shape)
     return all(int(d) % 8 == 0 for d in dims)

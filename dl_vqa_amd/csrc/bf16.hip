@@ -5,11 +5,15 @@
 // The convolution kernels of the bf16 path live in conv.hip (conv_bf16.inc).
 #include "bf16_core.hpp"
 #include "gemm_epilogue.hpp"
+#include <stdlib.h>
 
 namespace vqa {
 
 using CfgB128 = TileCfg<128, 128, 2, 2>;
 using CfgB64 = TileCfg<64, 64, 2, 2>;
+// 128 x 256: a weight-gradient product whose output is only 256 columns wide (v_conv dW: [mid] x [C = 256], K = B * positions) --
+// with two 128-column tiles the reduction-major A operand (dx', 3 GB) was fetched 1.7x (PMC); one tile spans all columns
+using CfgB128x256 = TileCfg<128, 256, 2, 2>;
 
 template <class Cfg, class AL, class BL>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void gemm_bf16_kernel(typename AL::Params pa,
@@ -163,6 +167,28 @@ int vqa_gemm_bf16(const void* A, int64_t lda, int transA, const void* B, int64_t
   }
   set_launch_tag(tag);
   ProfScope prof(VQA_K_GEMM, s);
+  static const int wide_ok = [] { const char* e = getenv("VQA_GEMM_WIDE"); return e && atoi(e) == 0 ? 0 : 1; }();
+  if (wide_ok && transA && !transB && N == 256 && M % 128 == 0 && K >= (1 << 16) && workspace) {
+    // long-K weight gradient with a 256-column output: 128 x 256 tiles, one workgroup per CU, split-K over the 256 slots
+    GemmPlan q = p;
+    q.big = 1;
+    q.tiles_m = M / 128;
+    q.tiles_n = 1;
+    int splits = 256 / q.tiles_m;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    q.ks_per_split = (q.nk + splits - 1) / splits;
+    q.splits = (q.nk + q.ks_per_split - 1) / q.ks_per_split;
+    q.order = 0;
+    if (workspace_bytes >= (int64_t)q.splits * M * N * 4) {
+      pe.slab = q.splits > 1 ? workspace : nullptr;
+      using Cfg = CfgB128x256;
+      int rc = launch_gemm_bf16<Cfg, PlainCb<Cfg::BM, Cfg::LT>, PlainCb<Cfg::BN, Cfg::LT>>({A, lda, M, K}, {B, ldb, N, K}, pe, q, s);
+      if (rc) return rc;
+      if (q.splits > 1) rc = launch_splitk_reduce(pe, q.splits, s);
+      return rc;
+    }
+  }
   int rc = p.big ? dispatch_gemm_bf16<CfgB128>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s)
                  : dispatch_gemm_bf16<CfgB64>(A, lda, transA, B, ldb, transB, pe, p, M, N, K, s);
   if (rc) return rc;

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][i], b[t & 1][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = RT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[t & 1][j], a[t & 1][i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][i], b[t & 1][j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a[t & 1][i]));
@@ -449,80 +450,80 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const PcParams P) {
           asm volatile("" ::: "memory");
         }
       }
-    } else if (EPI == 2) {
-      // rounds of one row tile (2 rows x 16 pixels) x the wave's 64 channels: [pixel][64 ch] bf16 through the scratch
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int pp = ((e >> 1) & 1) * 16 + 4 * (e >> 2) + 2 * h + (e & 1);
-            *reinterpret_cast<uint16_t*>(scr + pp * 128 + (32 * j + r) * 2) = bf16_bits(acc[i][j][e]);
-          }
-        asm volatile("" ::: "memory");
-        const int ya = y0 + wm * 4 + 2 * (i >> 1), xa = x0 + 16 * (i & 1);
-        const int64_t o0 = (((int64_t)img * P.Hc + ya) * P.Wc + xa) * P.N + n_slab0 + wn * 64;
-        const __amdgpu_buffer_rsrc_t ro = buf_rsrc(static_cast<uint16_t*>(P.out) + o0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int byte = q * 1024 + lane * 16;
-          const int pp = byte >> 7, inrun = byte & 127;
-          const int dy = pp >> 4, col = pp & 15;
-          const float4 v = *reinterpret_cast<const float4*>(scr + byte);
-          const bool ok = ya + dy < P.Hc && xa + col < P.Wc;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
-                                                 ok ? (int)((dy * P.Wc + col) * P.N * 2 + inrun) : (int)BUF_OOB, 0, 0);
-        }
-        asm volatile("" ::: "memory");
-      }
-    } else if (EPI == 4) {
-      // the same rounds, C16 output [B][N/16][Hc][Wc][16] (the pooled gradient of the block below, read by its routed patches):
-      // scratch [16-channel block][row][pixel][16], a 1-KiB store instruction = one block's 2 x 16 pixels
-      const int64_t cplane = (int64_t)P.Hc * P.Wc;
-      char* const scr4 = scr + ((r >> 4) * 32 + 2 * h) * 32 + (r & 15) * 2;
-      const int st_dy = lane >> 5, st_col = (lane >> 1) & 15;
-      const int st_off = (st_dy * P.Wc + st_col) * 32 + (lane & 1) * 16;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int pp = ((e >> 1) & 1) * 16 + 4 * (e >> 2) + (e & 1);          // + 2 h: in scr4
-            *reinterpret_cast<uint16_t*>(scr4 + (2 * j * 32 + pp) * 32) = bf16_bits(acc[i][j][e]);
-          }
-        asm volatile("" ::: "memory");
-        const int ya = y0 + wm * 4 + 2 * (i >> 1), xa = x0 + 16 * (i & 1);
-        const int64_t o0 = ((((int64_t)img * (P.N / 16) + (n_slab0 + wn * 64) / 16) * P.Hc + ya) * P.Wc + xa) * 16;
-        const __amdgpu_buffer_rsrc_t ro = buf_rsrc(static_cast<uint16_t*>(P.out) + o0);
-        const bool ok = ya + st_dy < P.Hc && xa + st_col < P.Wc;
-        const int vo = ok ? st_off : (int)BUF_OOB;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(scr + q * 1024 + lane * 16);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, q * (int)cplane * 32, 0);
-        }
-        asm volatile("" ::: "memory");
-      }
     } else {
-      float* const out32 = static_cast<float*>(P.out);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int colt = n_slab0 + wn * 64 + 32 * j;
+      // ---- backward-data epilogues.  The routed kernels multiply TRANSPOSED (weights as the A operand): lane (r, h) holds ONE
+      // pixel of the row tile -- (dy, col) = ((r >> 1) & 1, 2 (r >> 2) + (r & 1)) -- and, per register group e >> 2, four CONSECUTIVE
+      // channels 32 j + 8 (e >> 2) + 4 h ..: a group is one v_cvt_pk pair and one 8-byte LDS write (the pixel-in-registers form
+      // needed 128 conversions and 128 two-byte writes per wave and row-tile round; the epilogue was 0.3-0.5 ms of a 3 ms launch)
+      const int pdy = (r >> 1) & 1, pcol = 2 * (r >> 2) + (r & 1), pp_l = pdy * 16 + pcol;
+      if (EPI == 2) {
+        // [pixel][64 ch] bf16 through the scratch, pixel stride 144 bytes (two-way conflicts on the write, aligned 16-byte reads)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int ya = y0 + wm * 4 + 2 * (i >> 1);
-          const int xa = x0 + 16 * (i & 1);
-          const int64_t o0 = (((int64_t)img * P.Hc + ya) * P.Wc + xa) * P.N + colt;
-          const __amdgpu_buffer_rsrc_t ro = buf_rsrc(out32 + o0);
-          const uint32_t vl = (uint32_t)(2 * h * P.N + r) * 4u;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int g = e >> 2, dy = (e >> 1) & 1, dx = e & 1;
-            const bool ok = ya + dy < P.Hc && xa + 4 * g + 2 * h + dx < P.Wc;
-            buf_store4(ro, acc[i][j][e], ok ? vl : BUF_OOB, (uint32_t)((dy * P.Wc + 4 * g + dx) * P.N) * 4u);
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+              *reinterpret_cast<uint2*>(scr + pp_l * 144 + (32 * j + 8 * q4 + 4 * h) * 2) =
+                  make_uint2(pack_bf16x2(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1]), pack_bf16x2(acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]));
+          asm volatile("" ::: "memory");
+          const int ya = y0 + wm * 4 + 2 * (i >> 1), xa = x0 + 16 * (i & 1);
+          const int64_t o0 = (((int64_t)img * P.Hc + ya) * P.Wc + xa) * P.N + n_slab0 + wn * 64;
+          const __amdgpu_buffer_rsrc_t ro = buf_rsrc(static_cast<uint16_t*>(P.out) + o0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int pp = q * 8 + (lane >> 3), inrun = (lane & 7) * 16;
+            const int dy = pp >> 4, col = pp & 15;
+            const float4 v = *reinterpret_cast<const float4*>(scr + pp * 144 + inrun);
+            const bool ok = ya + dy < P.Hc && xa + col < P.Wc;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro,
+                                                   ok ? (int)((dy * P.Wc + col) * P.N * 2 + inrun) : (int)BUF_OOB, 0, 0);
           }
+          asm volatile("" ::: "memory");
+        }
+      } else if (EPI == 4) {
+        // C16 output [B][N/16][Hc][Wc][16] (the pooled gradient of the block below, read by its routed patches): per 32-channel
+        // half j the scratch holds [2 blocks][32 pixels][48 bytes] (32 used); a 1-KiB store instruction = one block's 2 x 16 pixels
+        const int64_t cplane = (int64_t)P.Hc * P.Wc;
+        const int st_dy = lane >> 5, st_col = (lane >> 1) & 15;
+        const int st_off = (st_dy * P.Wc + st_col) * 32 + (lane & 1) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ya = y0 + wm * 4 + 2 * (i >> 1), xa = x0 + 16 * (i & 1);
+          const int64_t o0 = ((((int64_t)img * (P.N / 16) + (n_slab0 + wn * 64) / 16) * P.Hc + ya) * P.Wc + xa) * 16;
+          const __amdgpu_buffer_rsrc_t ro = buf_rsrc(static_cast<uint16_t*>(P.out) + o0);
+          const bool ok = ya + st_dy < P.Hc && xa + st_col < P.Wc;
+          const int vo = ok ? st_off : (int)BUF_OOB;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+              *reinterpret_cast<uint2*>(scr + ((q4 >> 1) * 32 + pp_l) * 48 + (8 * (q4 & 1) + 4 * h) * 2) =
+                  make_uint2(pack_bf16x2(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1]), pack_bf16x2(acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]));
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {            // block 2 j + u: lane = (pixel, 16-byte half)
+              const float4 v = *reinterpret_cast<const float4*>(scr + (u * 32 + (lane >> 1)) * 48 + (lane & 1) * 16);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, (2 * j + u) * (int)cplane * 32, 0);
+            }
+            asm volatile("" ::: "memory");
+          }
+        }
+      } else {
+        // fp32 NHWC (tests): one dword per register, lane = pixel
+        float* const out32 = static_cast<float*>(P.out);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ya = y0 + wm * 4 + 2 * (i >> 1) + pdy, xa = x0 + 16 * (i & 1) + pcol;
+          const int64_t o0 = (int64_t)img * P.Hc * P.Wc * P.N + n_slab0 + wn * 64;
+          const __amdgpu_buffer_rsrc_t ro = buf_rsrc(out32 + o0);
+          const bool ok = ya < P.Hc && xa < P.Wc;
+          const uint32_t vl = ok ? (uint32_t)(((ya * P.Wc + xa) * P.N + 4 * h) * 4) : BUF_OOB;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              buf_store4(ro, acc[i][j][e], vl, (uint32_t)((32 * j + 8 * (e >> 2) + (e & 3)) * 4));
         }
       }
     }

@@ -48,12 +48,13 @@ def test_converters_round_to_nearest_even():
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (304, 200, 96), (64, 64, 64), (8, 8, 8), (256, 1024, 2560),
-                                   (1032, 264, 3584), (136, 4096, 304), (72, 56, 40), (200, 136, 1000), (384, 256, 66008)])
+                                   (1032, 264, 3584), (136, 4096, 304), (72, 56, 40), (200, 136, 1000), (384, 256, 66008), (65544, 256, 328)])
 @pytest.mark.parametrize("transA,transB", [(False, True), (False, False), (True, True), (True, False)])
 def test_gemm_bf16_layouts(M, N, K, transA, transB):
     """Every operand layout: k-contiguous rows (the fp32 engine's LDS image reused) and reduction-major rows (the
     ds_read_b64_tr_b16 transpose-read image); asymmetric random data, tiles with edges, K tails, split-K plans; the last
-    shape with transA / not transB is the long-K weight gradient with a 256-column output (128 x 256 tiles, K tail of 8)."""
+    but one shape with transA / not transB is the long-K weight gradient with a 256-column output (128 x 256 tiles, K tail of 8), the
+    last one is a tall product with a ragged last row tile and a K tail (the v_conv backward-data shape class)."""
     ops = _ops()
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = rb(torch.randn(M, K, generator=g))

@@ -50,6 +50,12 @@ PROTOTYPES = {
     "vqa_conv3x3_wgrad_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "vqa_conv3x3_wgrad": (i32, [f32p, f32p, u8p, f32p, f32p, i32, i32, i32, i32, i32, i32, i32,
                                 f32p, i64, i32, vp]),
+    "vqa_convk_pack_weights": (i32, [f32p, f32p, i32, i32, i32, i32, vp]),
+    "vqa_convk_unpack_wgrad": (i32, [f32p, f32p, i32, i32, i32, i32, vp]),
+    "vqa_convk_im2col": (i32, [f32p, f32p, i32, i32, i32, i32, i32, i32, vp]),
+    "vqa_convk_relu_pool": (i32, [f32p, f32p, u8p, i32, i32, i32, i32, vp]),
+    "vqa_convk_route": (i32, [f32p, u8p, f32p, i32, i32, i32, i32, vp]),
+    "vqa_convk_col2im": (i32, [f32p, f32p, i32, i32, i32, i32, i32, i32, vp]),
     "vqa_conv3x3_x3_supported": (i32, [i32, i32, i32, i32, i32]),
     "vqa_x3_split": (i32, [f32p, vp, vp, vp, i64, vp]),
     "vqa_x3_pack": (i32, [f32p, vp, i64, vp]),

@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libvqa_hip.so")
 SOURCES = ([("gemm.hip", f"_p{k}", [f"-DVQA_GEMM_PART={k}"]) for k in (2, 3, 4, 5)]
            + [("gemm_x3.hip", f"_p{k}", [f"-DVQA_GEMM_PART={k}"]) for k in (1, 2, 3, 4)]
            + ["bf16.hip", ("gemm.hip", "_p1", ["-DVQA_GEMM_PART=1"]), "conv.hip", "conv_x3.hip", "conv_bf16.hip", "conv_patch_bf16.hip", "conv_patch_f32.hip", "gemm_tall_bf16.hip", "gemm.hip",
-              "gemm_x3.hip", "conv0.hip", "lstm.hip", "elementwise.hip"])
+              "gemm_x3.hip", "conv0.hip", "lstm.hip", "elementwise.hip", "conv_generic.hip"])
 HEADERS = ["common.hpp", "gemm_core.hpp", "gemm_epilogue.hpp", "bf16_core.hpp", "x3_core.hpp", "conv_device.inc", "conv_host.inc", "conv_bf16.inc", os.path.join("..", "..", "include", "vqa_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

@@ -39,8 +39,11 @@ class Engine:
         self.channels = list(i["num_channels"])
         self.L = len(self.channels) - 1
         self.stride = i["stride"]
-        if i["kernel_size"] != 3:
-            raise NotImplementedError("only kernel_size=3 (config.yaml:58) has a HIP kernel")
+        # kernel_size 3 (config.yaml:58) has the implicit-GEMM / patch kernels; any other size the schema admits
+        # (utils/config_schema.py:59) takes the materialised im2col + GEMM form (csrc/conv_generic.hip), fp32 only
+        self.ks = int(i["kernel_size"])
+        if not 1 <= self.ks <= 15:
+            raise ValueError(f"image.kernel_size={self.ks}: 1..15")
         self.mid = a["hidden_dim"]
         self.G = a["glimpses"]
         self.do_option = a["do_option"]
@@ -68,6 +71,8 @@ class Engine:
         # fp32 operand split exactly into three bf16 terms (csrc/x3_core.hpp) -- fp32-level accuracy, opt-in.
         if compute_dtype not in ("fp32", "bf16", "fp32x3"):
             raise ValueError(f"compute_dtype {compute_dtype!r} (fp32, fp32x3 or bf16)")
+        if self.ks != 3 and compute_dtype != "fp32":
+            raise ValueError(f"compute_dtype {compute_dtype!r} needs image.kernel_size=3 (kernel_size={self.ks} runs in fp32)")
         self.bf16 = compute_dtype == "bf16"
         self.x3 = compute_dtype == "fp32x3"
         self.x3_gemm = self.x3 and os.environ.get("VQA_X3_GEMM", "1") != "0"     # diagnostic switch, read once
@@ -245,7 +250,7 @@ class Engine:
         # ---- image encoder: conv+relu+pool x L (models/model.py:79-84)
         # the first block has a dedicated kernel that reads the NCHW image as is (K = 27 is too thin for the
         # generic implicit GEMM); otherwise the image is converted to NHWC4 once
-        fast0 = ops.conv0_supported(v.shape[1], v.shape[2], v.shape[3], self.channels[1], self.stride)
+        fast0 = self.ks == 3 and ops.conv0_supported(v.shape[1], v.shape[2], v.shape[3], self.channels[1], self.stride)
         if v.dtype == torch.float16 and not fast0:
             # the dedicated first-block kernels read the dataset's fp16 features as they are (widened where the LDS patch is
             # staged); only shapes they do not cover take a widened copy through the generic NHWC path
@@ -261,6 +266,13 @@ class Engine:
             assert w.shape[0] == self.channels[l + 1]
             # fp32x3: a block whose successor runs on the split kernels writes its output x3-packed (split once per
             # tensor by the producer's epilogue; forward and wgrad of the successor read that form)
+            if self.ks != 3:
+                wk = ops.convk_pack_weights(w, acts[-1].shape[3])
+                pooled, am = ops.convk_fwd(acts[-1], wk, P[f"image.conv{l}.bias"], self.ks, self.stride, tag=l)
+                acts.append(pooled)
+                idxs.append(am)
+                wds.append(wk)
+                continue
             nxt_x3 = l + 1 < self.L and self._x3_layer(self._out_shape(acts[-1], l, fast0), self.channels[l + 2])
             if l == 0 and fast0:
                 pooled, am = ops.conv0_fwd(v, w, P["image.conv0.bias"],
@@ -612,6 +624,10 @@ class Engine:
             dP = ops.l2norm_bwd(dvn, ctx.vn, ctx.norm, ctx.p_img, sd(SITE_IMAGE),
                                 out_dtype=torch.bfloat16 if self.bf16 else torch.float32).view_as(ctx.acts[-1])
         for l in range(self.L - 1, -1, -1):
+            if self.ks != 3:
+                dP = ops.convk_bwd(ctx.acts[l], dP, ctx.idxs[l], ctx.wds[l], Gr[f"image.conv{l}.weight"], Gr[f"image.conv{l}.bias"],
+                                   self.ks, self.stride, need_dx=l > 0, tag=l)
+                continue
             if l == 0 and ctx.fast0:
                 if self.bf16:
                     ops.conv0_wgrad_bf16(ctx.acts[0], dP, ctx.idxs[0], Gr["image.conv0.weight"], Gr["image.conv0.bias"])

@@ -67,6 +67,84 @@ def conv_out_hw(H: int, W: int, stride: int) -> Tuple[int, int]:
     return ((H - 3) // stride + 1) // 2, ((W - 3) // stride + 1) // 2
 
 
+def convk_out_hw(H: int, W: int, ks: int, stride: int) -> Tuple[int, int, int, int]:
+    """(Ho, Wo, Hp, Wp) of Conv2d(kernel_size=ks, stride, pad=0) -> MaxPool2d(2,2) (models/model.py:80-82)."""
+    Ho, Wo = (H - ks) // stride + 1, (W - ks) // stride + 1
+    return Ho, Wo, Ho // 2, Wo // 2
+
+
+def convk_pack_weights(w: torch.Tensor, CiP: int) -> torch.Tensor:
+    """torch [Co][Ci][ks][ks] -> wk [Co][ks*ks*CiP], K index (ky*ks + kx)*CiP + ci (the im2col matrix's)."""
+    Co, Ci, ks, ks2 = w.shape
+    assert ks == ks2
+    wk = torch.empty(Co, ks * ks * CiP, dtype=torch.float32, device=w.device)
+    call("vqa_convk_pack_weights", ptr(w), ptr(wk), Co, Ci, CiP, ks, stream())
+    return wk
+
+
+def convk_unpack_wgrad(dwk: torch.Tensor, dw: torch.Tensor, CiP: int) -> torch.Tensor:
+    Co, Ci, ks, _ = dw.shape
+    call("vqa_convk_unpack_wgrad", ptr(dwk), ptr(dw), Co, Ci, CiP, ks, stream())
+    return dw
+
+
+def convk_chunk(B: int, H: int, W: int, CiP: int, Co: int, ks: int, stride: int, limit_bytes: int = 1 << 31) -> int:
+    """Images per im2col chunk: the matrix [rows][ks*ks*CiP] (and the GEMM's [rows][Co] result) stay below limit_bytes."""
+    Ho, Wo, _, _ = convk_out_hw(H, W, ks, stride)
+    per_img = Ho * Wo * max(ks * ks * CiP, Co) * 4
+    return max(1, min(B, limit_bytes // per_img))
+
+
+def convk_fwd(x: torch.Tensor, wk: torch.Tensor, bias: torch.Tensor, ks: int, stride: int = 1, tag: int = 0, chunk: int = 0):
+    """Conv block with kernel_size != 3, materialised form (csrc/conv_generic.hip): x NHWC [B,H,W,CiP] ->
+    (pooled [B,Hp,Wp,Co], arg-max bytes).  im2col of a batch chunk, vqa_gemm with the bias in its epilogue, ReLU + pool."""
+    B, H, W, CiP = x.shape
+    Co, K = wk.shape
+    assert K == ks * ks * CiP and x.dtype == torch.float32 and x.is_contiguous()
+    Ho, Wo, Hp, Wp = convk_out_hw(H, W, ks, stride)
+    assert Hp > 0 and Wp > 0, "image too small for conv + pool"
+    pooled = torch.empty(B, Hp, Wp, Co, dtype=torch.float32, device=x.device)
+    amax = torch.empty(B, Hp, Wp, Co, dtype=torch.uint8, device=x.device)
+    nb = chunk or convk_chunk(B, H, W, CiP, Co, ks, stride)
+    cols = torch.empty(nb * Ho * Wo, K, dtype=torch.float32, device=x.device)
+    y = torch.empty(nb * Ho * Wo, Co, dtype=torch.float32, device=x.device)
+    for b0 in range(0, B, nb):
+        n = min(nb, B - b0)
+        call("vqa_convk_im2col", ptr(x[b0:]), ptr(cols), n, H, W, CiP, ks, stride, stream())
+        gemm(cols, wk, y, n * Ho * Wo, Co, K, transB=True, bias1=bias, tag=tag)
+        call("vqa_convk_relu_pool", ptr(y), ptr(pooled[b0:]), ptr(amax[b0:]), n, Ho, Wo, Co, stream())
+    return pooled, amax
+
+
+def convk_bwd(x: torch.Tensor, dpooled: torch.Tensor, amax: torch.Tensor, wk: torch.Tensor, dw: torch.Tensor,
+              dbias: torch.Tensor, ks: int, stride: int = 1, need_dx: bool = True, tag: int = 0, chunk: int = 0):
+    """Backward of convk_fwd: dw [Co][Ci][ks][ks] and dbias are written, dX NHWC is returned (None if not need_dx)."""
+    B, H, W, CiP = x.shape
+    Co, K = wk.shape
+    Ho, Wo, Hp, Wp = convk_out_hw(H, W, ks, stride)
+    assert dpooled.shape == (B, Hp, Wp, Co) and dpooled.dtype == torch.float32 and dpooled.is_contiguous()
+    nb = chunk or convk_chunk(B, H, W, CiP, Co, ks, stride)
+    cols = torch.empty(nb * Ho * Wo, K, dtype=torch.float32, device=x.device)
+    dy = torch.empty(nb * Ho * Wo, Co, dtype=torch.float32, device=x.device)
+    dcols = torch.empty(nb * Ho * Wo, K, dtype=torch.float32, device=x.device) if need_dx else None
+    dwk = torch.empty(Co, K, dtype=torch.float32, device=x.device)
+    dx = torch.empty(B, H, W, CiP, dtype=torch.float32, device=x.device) if need_dx else None
+    for b0 in range(0, B, nb):
+        n = min(nb, B - b0)
+        rows = n * Ho * Wo
+        call("vqa_convk_route", ptr(dpooled[b0:]), ptr(amax[b0:]), ptr(dy), n, Ho, Wo, Co, stream())
+        call("vqa_convk_im2col", ptr(x[b0:]), ptr(cols), n, H, W, CiP, ks, stride, stream())
+        # dWk [Co][K] (+)= dY^T . cols over the chunk's rows
+        gemm(dy, cols, dwk, Co, K, rows, transA=True, transB=False, accumulate=b0 > 0, tag=tag)
+        if need_dx:
+            gemm(dy, wk, dcols, rows, K, Co, transA=False, transB=False, tag=tag)
+            call("vqa_convk_col2im", ptr(dcols), ptr(dx[b0:]), n, H, W, CiP, ks, stride, stream())
+    convk_unpack_wgrad(dwk, dw, CiP)
+    # windows whose ReLU was dead (arg-max byte 4) pass no gradient to the bias either
+    colsum(dpooled, B * Hp * Wp, Co, dbias, mask=amax)
+    return dx
+
+
 def x3_split(x: torch.Tensor) -> torch.Tensor:
     """The exact three-way bf16 split of the fp32x3 kernels: x (fp32, numel % 4 == 0) -> planes [3, *x.shape] bf16
     (hi, mid, lo) with x == hi + mid + lo."""

@@ -28,7 +28,7 @@ extern "C" {
 
 /* Bumped whenever an exported entry point changes its argument list or disappears (round 1: 1, round 2: 2, round 3: 3).
  * dl_vqa_amd/_lib.py parses this line and refuses a library that answers differently. */
-#define VQA_ABI_VERSION 6
+#define VQA_ABI_VERSION 7
 
 #define VQA_OK 0
 #define VQA_ERR_INVALID 1 /* bad argument (shape, alignment, null pointer) */
@@ -113,6 +113,21 @@ int64_t vqa_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int CiP, int Co, 
 int vqa_conv3x3_wgrad(const float* x, const float* dpooled, const uint8_t* argmax, float* dw,
                       float* dbias, int B, int H, int W, int CiP, int Ci, int Co, int stride,
                       float* workspace, int64_t workspace_bytes, int tag, vqa_stream_t stream);
+
+/* Conv blocks with image.kernel_size != 3 (models/model.py:75-82: nn.Conv2d(kernel_size=k, stride) -> ReLU -> MaxPool2d(2,2);
+ * utils/config_schema.py:59 admits any int, config.yaml:58 ships 3): the materialised form of the same product
+ * (csrc/conv_generic.hip).  The caller writes the im2col matrix of a batch chunk, runs vqa_gemm on it (bias in the GEMM's
+ * epilogue, relu = 0) and pools; backward routes the pooled gradient to the pre-pool rows, takes dW = dY^T.cols and
+ * dcols = dY.wk with vqa_gemm and folds dcols back.  Ho = (H - ks)/stride + 1, rows r = (b*Ho + yo)*Wo + xo, K index
+ * (ky*ks + kx)*CiP + ci; ks in 1..15, stride 1 or 2, CiP % 4 == 0, Co % 4 == 0; arg-max bytes as above (0..3, 4 = dead).
+ *   wk [Co][ks*ks*CiP] from torch's [Co][Ci][ks][ks] (channels >= Ci zero); vqa_convk_unpack_wgrad is its inverse for dW. */
+int vqa_convk_pack_weights(const float* w, float* wk, int Co, int Ci, int CiP, int ks, vqa_stream_t stream);
+int vqa_convk_unpack_wgrad(const float* dwk, float* dw, int Co, int Ci, int CiP, int ks, vqa_stream_t stream);
+int vqa_convk_im2col(const float* x, float* cols, int B, int H, int W, int CiP, int ks, int stride, vqa_stream_t stream);
+/* y [B*Ho*Wo][Co] = the convolution output with its bias, before the ReLU */
+int vqa_convk_relu_pool(const float* y, float* pooled, uint8_t* argmax, int B, int Ho, int Wo, int Co, vqa_stream_t stream);
+int vqa_convk_route(const float* dpooled, const uint8_t* argmax, float* dy, int B, int Ho, int Wo, int Co, vqa_stream_t stream);
+int vqa_convk_col2im(const float* dcols, float* dx, int B, int H, int W, int CiP, int ks, int stride, vqa_stream_t stream);
 
 /* First conv block, dedicated path (Cin <= 3, stride 1, Co in {32, 64}, W % 4 == 0): reads the caller's
  * NCHW image directly (no layout conversion), weights/bias in torch layout, same pooled/argmax outputs

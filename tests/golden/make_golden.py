@@ -6,7 +6,7 @@ GPU box and nothing at test time imports this script's dependencies):
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
 What is recorded (data only: inputs and expected outputs, no reference source):
-  tiny_{plus,mul,cat,stride2,uni}.npz
+  tiny_{plus,mul,cat,stride2,uni,k5,k2_stride2,k1}.npz
       inputs, the full state_dict, per-stage activations, logits, loss, VQA score
       and the gradient of every parameter, all produced by the imported
       ``models.model.VqaNet`` in eval mode (dropout = identity) with autograd.
@@ -38,11 +38,11 @@ from models.model import VqaNet  # noqa: E402  (reference, build container only)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def tiny_cfg(do_option="+", stride=1, bidirectional=True):
+def tiny_cfg(do_option="+", stride=1, bidirectional=True, kernel_size=3):
     return {
         "text": {"question_features": 16, "embedding_features": 12, "dropout": 0.3,
                  "num_lstm_layers": 1, "bidirectional": bidirectional},
-        "image": {"kernel_size": 3, "dropout": 0.3, "num_channels": [3, 8, 16, 32],
+        "image": {"kernel_size": kernel_size, "dropout": 0.3, "num_channels": [3, 8, 16, 32],
                   "stride": stride, "do_skip_connection": False},
         "attention": {"hidden_dim": 24, "glimpses": 2, "do_option": do_option, "dropout": 0.3},
         "classifier": {"hidden_dim": 20, "dropout": 0.3},
@@ -129,8 +129,8 @@ def run_reference(model, v, q, q_len, a_idx, a_val, a_len, capture=True, train=F
     return y.detach(), loss.detach(), score, grads, stages
 
 
-def tiny_case(name, do_option="+", stride=1, bidirectional=True, S=32, seed=1):
-    cfg = tiny_cfg(do_option, stride, bidirectional)
+def tiny_case(name, do_option="+", stride=1, bidirectional=True, S=32, seed=1, kernel_size=3):
+    cfg = tiny_cfg(do_option, stride, bidirectional, kernel_size)
     V, A, B, T = 50, cfg["max_answers"], 3, 5
     torch.manual_seed(seed)
     model = VqaNet(cfg, V)
@@ -147,10 +147,19 @@ def tiny_case(name, do_option="+", stride=1, bidirectional=True, S=32, seed=1):
     for k, t in stages.items():
         out["stage/" + k] = t
     meta = dict(do_option=do_option, stride=stride, bidirectional=bidirectional, S=S, V=V, seed=seed)
+    if kernel_size != 3:
+        meta["kernel_size"] = kernel_size
     np.savez_compressed(os.path.join(HERE, name + ".npz"),
                         **{k: t.numpy() for k, t in out.items()},
                         meta=np.array(repr(meta)))
     print(name, "loss", float(loss), "score", float(score), "logits[0,:3]", y[0, :3].tolist())
+
+
+def kernel_size_cases():
+    """image.kernel_size != 3 (utils/config_schema.py:59 admits any int; models/model.py:75-80): 5x5, 2x2 with stride 2, 1x1."""
+    tiny_case("tiny_k5", "+", S=64, seed=5, kernel_size=5)
+    tiny_case("tiny_k2_stride2", "*", stride=2, S=128, seed=6, kernel_size=2)
+    tiny_case("tiny_k1", "|", S=32, seed=7, kernel_size=1)
 
 
 class MaskDrop(torch.nn.Module):
@@ -242,6 +251,9 @@ if __name__ == "__main__":
         for nm, op in (("tiny_plus_train", "+"), ("tiny_mul_train", "*"), ("tiny_cat_train", "|")):
             train_case(nm, op)
         sys.exit(0)
+    if "--kernel-only" in sys.argv:     # add the kernel_size != 3 fixtures without rewriting the others
+        kernel_size_cases()
+        sys.exit(0)
     tiny_case("tiny_plus", "+")
     tiny_case("tiny_mul", "*")
     tiny_case("tiny_cat", "|")
@@ -251,4 +263,5 @@ if __name__ == "__main__":
     tiny_case("small64_plus", "+", S=64, seed=3)
     for nm, op in (("tiny_plus_train", "+"), ("tiny_mul_train", "*"), ("tiny_cat_train", "|")):
         train_case(nm, op)
+    kernel_size_cases()
     full_case()

@@ -7,7 +7,9 @@ import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-TINY_CASES = ["tiny_plus", "tiny_mul", "tiny_cat", "tiny_stride2", "tiny_uni", "small64_plus"]
+TINY_CASES = ["tiny_plus", "tiny_mul", "tiny_cat", "tiny_stride2", "tiny_uni", "small64_plus",
+              # image.kernel_size != 3 (make_golden.kernel_size_cases)
+              "tiny_k5", "tiny_k2_stride2", "tiny_k1"]
 # reference model in train mode with the dropout masks recorded as data (make_golden.train_case)
 TRAIN_CASES = ["tiny_plus_train", "tiny_mul_train", "tiny_cat_train"]
 
@@ -16,7 +18,7 @@ def tiny_cfg(meta):
     return {
         "text": {"question_features": 16, "embedding_features": 12, "dropout": 0.3,
                  "num_lstm_layers": 1, "bidirectional": meta["bidirectional"]},
-        "image": {"kernel_size": 3, "dropout": 0.3, "num_channels": [3, 8, 16, 32],
+        "image": {"kernel_size": meta.get("kernel_size", 3), "dropout": 0.3, "num_channels": [3, 8, 16, 32],
                   "stride": meta["stride"], "do_skip_connection": False},
         "attention": {"hidden_dim": 24, "glimpses": 2, "do_option": meta["do_option"], "dropout": 0.3},
         "classifier": {"hidden_dim": 20, "dropout": 0.3},

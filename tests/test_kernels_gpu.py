@@ -251,6 +251,49 @@ def test_pconvf_dgrad_matches_the_implicit_gemm_kernel_and_float64(B, H, W, Ci, 
     check(f"pconvf dgrad {B,H,W,Ci,Co}", got.permute(0, 3, 1, 2), dx_ref, 3e-6 * math.sqrt(9 * Co))
 
 
+CONVK_CASES = [  # B, H, W, Ci, Co, ks, stride, images per im2col chunk (0 = one chunk)
+    (2, 20, 20, 8, 16, 5, 1, 0),
+    (3, 23, 27, 3, 8, 5, 1, 2),      # Ci = 3 padded to 4, odd sizes, a ragged last chunk
+    (2, 33, 35, 8, 12, 2, 2, 1),     # even kernel, stride 2, one image per chunk (wgrad accumulates over chunks)
+    (2, 17, 19, 16, 8, 1, 1, 0),     # 1 x 1
+    (1, 30, 31, 12, 20, 7, 2, 0),    # 7 x 7, stride 2
+    (2, 26, 26, 64, 128, 4, 1, 0),   # MFMA-sized channel counts
+]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,ks,stride,chunk", CONVK_CASES)
+def test_convk_block_fwd_bwd(B, H, W, Ci, Co, ks, stride, chunk):
+    """image.kernel_size != 3 (csrc/conv_generic.hip: im2col + vqa_gemm + pool / route / col2im) against float64 autograd of
+    Conv2d(k, stride) -> ReLU -> MaxPool2d(2,2) (models/model.py:80-82)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Ci + ks)
+    CiP = (Ci + 3) // 4 * 4
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, ks, ks, generator=g) / math.sqrt(ks * ks * Ci)
+    b = torch.randn(Co, generator=g) * 0.1
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.max_pool2d(torch.relu(F.conv2d(xr, wr, br, stride=stride)), 2, 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    xd = _nhwc(x, CiP).to(DEV)
+    wk = ops.convk_pack_weights(w.to(DEV), CiP)
+    pooled, amax = ops.convk_fwd(xd, wk, b.to(DEV), ks, stride, chunk=chunk)
+    torch.cuda.synchronize()
+    check(f"convk fwd {B,H,W,Ci,Co,ks,stride}", pooled.permute(0, 3, 1, 2), yr, 3e-6 * math.sqrt(ks * ks * Ci))
+    assert bool(((pooled == 0) == (amax == 4)).all()), "arg-max code 4 must mark exactly the zero outputs"
+    dw = torch.empty(Co, Ci, ks, ks, device=DEV)
+    db = torch.empty(Co, device=DEV)
+    dx = ops.convk_bwd(xd, _nhwc(dy).to(DEV), amax, wk, dw, db, ks, stride, need_dx=True, chunk=chunk)
+    torch.cuda.synchronize()
+    check("convk dgrad", dx[..., :Ci].permute(0, 3, 1, 2), xr.grad, 5e-6 * math.sqrt(ks * ks * Co))
+    if CiP != Ci:
+        assert float(dx[..., Ci:].abs().max()) == 0.0
+    check("convk wgrad", dw, wr.grad, 2e-5)
+    check("convk bias grad", db, br.grad, 2e-5)
+    assert ops.convk_bwd(xd, _nhwc(dy).to(DEV), amax, wk, dw, db, ks, stride, need_dx=False, chunk=chunk) is None
+
+
 def test_nchw_to_nhwc4():
     ops = _ops()
     x = torch.randn(2, 3, 9, 11)

@@ -57,6 +57,22 @@ def test_unsupported_configs_fail_loudly():
     m = VqaNet(cfg, 10)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 32, 32), torch.ones(1, 3, dtype=torch.int64), torch.tensor([3]))
+    # num_lstm_layers > 1: the reference constructs but its own forward raises (questionNet returns [B, layers*ndir*H] while
+    # q_lin / lin1 are sized for ndir*H, models/model.py:36,166,174; "needs change of code if >1", config.yaml:55 -- run here:
+    # RuntimeError "mat1 and mat2 shapes cannot be multiplied (3x64 and 32x24)").  The mirror refuses at construction.
+    cfg = tiny_cfg(dict(bidirectional=True, stride=1, do_option="+"))
+    cfg["text"]["num_lstm_layers"] = 2
+    with pytest.raises(NotImplementedError, match="num_lstm_layers"):
+        VqaNet(cfg, 10)
+    # every kernel_size of the schema constructs (3: implicit-GEMM kernels, others: csrc/conv_generic.hip); the opt-in
+    # compute modes are 3 x 3 only
+    for ks in (1, 2, 5):
+        cfg = tiny_cfg(dict(bidirectional=True, stride=1, do_option="+", kernel_size=ks))
+        assert tuple(VqaNet(cfg, 10).image.conv0.weight.shape) == (8, 3, ks, ks)
+    cfg = tiny_cfg(dict(bidirectional=True, stride=1, do_option="+", kernel_size=5))
+    cfg["image"]["num_channels"] = [3, 64, 64, 128]
+    with pytest.raises(ValueError, match="kernel_size"):
+        VqaNet(cfg, 10, compute_dtype="bf16")
 
 
 def test_lr_schedule():

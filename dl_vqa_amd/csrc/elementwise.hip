@@ -67,6 +67,60 @@ __global__ void l2norm_fwd_kernel(const float* pooled, float* vn, float* norm, i
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int nch = C >> 2;
+  if (nch <= 64) {
+    // C <= 256 (every config of the reference): a lane keeps its 4 channels in registers -- one pass over memory instead of
+    // two -- and a wave has FOUR rows in flight (one 1-KB row per wave left the CU with 32 KB in flight: 3.9 TB/s).  Same
+    // operations on every element as the general form below.
+    constexpr int R = 4;
+    const int c = lane;
+    const bool cok = c < nch;
+    for (int64_t r0 = R * wave; r0 < rows; r0 += R * nwaves) {
+      float4 u[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        u[k] = (cok && r0 + k < rows) ? reinterpret_cast<const float4*>(pooled + (r0 + k) * C)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float ss[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (p > 0.f) {
+          const uint64_t e = (uint64_t)(r0 + k) * C + 4 * c;
+          const float4 ds_ = drop_scale4(seed, e, p, inv_keep);
+          u[k].x *= ds_.x; u[k].y *= ds_.y; u[k].z *= ds_.z; u[k].w *= ds_.w;
+        }
+        ss[k] = 0.f;
+        ss[k] += u[k].x * u[k].x + u[k].y * u[k].y + u[k].z * u[k].z + u[k].w * u[k].w;
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) ss[k] = wave_sum(ss[k]);
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int64_t r = r0 + k;
+        if (r >= rows) break;
+        const float nrm = sqrtf(ss[k]);
+        const float inv = 1.0f / (nrm + 1e-12f);
+        if (lane == 0) norm[r] = nrm;
+        if (!cok) continue;
+        const float4 o = make_float4(u[k].x * inv, u[k].y * inv, u[k].z * inv, u[k].w * inv);
+        reinterpret_cast<float4*>(vn + r * C)[c] = o;
+        if (vdrop) {
+          const uint64_t e = (uint64_t)r * C + 4 * c;
+          float4 d = o;
+          if (p2 > 0.f) {
+            const float4 ds_ = drop_scale4(seed2, e, p2, inv_keep2);
+            d.x *= ds_.x; d.y *= ds_.y; d.z *= ds_.z; d.w *= ds_.w;
+          }
+          if (VB) {
+            uint2 w;
+            w.x = f2bf16_pair(d.x, d.y); w.y = f2bf16_pair(d.z, d.w);
+            reinterpret_cast<uint2*>(static_cast<uint16_t*>(vdrop) + r * C)[c] = w;
+          } else {
+            reinterpret_cast<float4*>(static_cast<float*>(vdrop) + r * C)[c] = d;
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float4* src = reinterpret_cast<const float4*>(pooled + r * C);
     float ss = 0.f;
@@ -537,6 +591,64 @@ __global__ void att_score_fwd_kernel(const void* xs, const float* wx, int wx_ld,
       const float v = wave_sum(acc[g]);
       if (lane == 0) score[(b * G + g) * P + pp] = v + bx[g];
     }
+  }
+}
+
+// fp32 x without the concatenated half, mid a multiple of 256 up to 1024 (the reference's 1024): the general kernel above walks
+// a row in mid/256 DEPENDENT rounds of 16-byte loads with one row per wave in flight and re-reads the x_conv weights for every
+// row (3.9 TB/s).  Here a lane issues all IT loads of a row before it touches the first value, the next row's loads are issued
+// before the current row is reduced, and the weights live in registers.  Same per-lane operation order as the general kernel.
+template <int G, int IT>
+__global__ __launch_bounds__(256) void att_score_fwd_rows_kernel(const float* xs, const float* wx, int wx_ld, const float* bx,
+                                                                 float* score, int64_t M, int P, float p, float inv_keep,
+                                                                 uint64_t seed) {
+  constexpr int mid = 256 * IT;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float4 w[IT][G];
+#pragma unroll
+  for (int i = 0; i < IT; ++i)
+#pragma unroll
+    for (int g = 0; g < G; ++g) w[i][g] = reinterpret_cast<const float4*>(wx + (int64_t)g * wx_ld)[lane + 64 * i];
+  float bias[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bias[g] = bx[g];
+  float4 cur[IT], nxt[IT];
+  int64_t m = wave;
+  if (m < M) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) cur[i] = reinterpret_cast<const float4*>(xs + m * mid)[lane + 64 * i];
+  }
+  for (; m < M; m += nwaves) {
+    const int64_t mn = m + nwaves;
+    if (mn < M) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) nxt[i] = reinterpret_cast<const float4*>(xs + mn * mid)[lane + 64 * i];
+    }
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      float4 x = cur[i];
+      if (p > 0.f) {
+        const uint64_t e = (uint64_t)m * mid + 4 * (lane + 64 * i);
+        const float4 ds_ = drop_scale4(seed, e, p, inv_keep);
+        x.x *= ds_.x; x.y *= ds_.y; x.z *= ds_.z; x.w *= ds_.w;
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] += x.x * w[i][g].x + x.y * w[i][g].y + x.z * w[i][g].z + x.w * w[i][g].w;
+    }
+    const int64_t b = m / P;
+    const int pp = (int)(m - b * P);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float v = wave_sum(acc[g]);
+      if (lane == 0) score[(b * G + g) * P + pp] = v + bias[g];
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -1242,6 +1354,21 @@ int vqa_att_score_fwd(const void* xs, int xs_is_bf16, const float* wx, int wx_ld
   } else if (xs_is_bf16) {
     DISPATCH_G(G, hipLaunchKernelGGL((att_score_fwd_kernel<kG, true>), dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx,
                                      wx_ld, bx, score, M, P, mid, p, KEEP(p), seed, qcat));
+  } else if (!qcat && G <= 2 && mid % 256 == 0 && mid <= 1024 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0) {
+#define ROWS_LAUNCH(kG, kIT)                                                                                                  \
+  hipLaunchKernelGGL((att_score_fwd_rows_kernel<kG, kIT>), dim3(grid_for(M, 4)), dim3(256), 0, STREAM,                        \
+                     static_cast<const float*>(xs), wx, wx_ld, bx, score, M, P, p, KEEP(p), seed)
+    switch ((G - 1) * 4 + mid / 256 - 1) {
+      case 0: ROWS_LAUNCH(1, 1); break;
+      case 1: ROWS_LAUNCH(1, 2); break;
+      case 2: ROWS_LAUNCH(1, 3); break;
+      case 3: ROWS_LAUNCH(1, 4); break;
+      case 4: ROWS_LAUNCH(2, 1); break;
+      case 5: ROWS_LAUNCH(2, 2); break;
+      case 6: ROWS_LAUNCH(2, 3); break;
+      default: ROWS_LAUNCH(2, 4); break;
+    }
+#undef ROWS_LAUNCH
   } else {
     DISPATCH_G(G, hipLaunchKernelGGL((att_score_fwd_kernel<kG, false>), dim3(grid_for(M, 4)), dim3(256), 0, STREAM, xs, wx,
                                      wx_ld, bx, score, M, P, mid, p, KEEP(p), seed, qcat));

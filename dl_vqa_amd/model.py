@@ -96,6 +96,21 @@ def _flat_order(names: List[str]) -> List[str]:
     return sorted(names, key=key)
 
 
+def validate_question_lengths(q_len, T: int) -> None:
+    """pack_padded_sequence (models/model.py:159-162) raises for a length below 1 or above the padded width.  Lengths that
+    arrive on the host (the data loader's, before run_batch uploads them) are checked there; device-resident lengths are
+    taken as they are -- the recurrence kernels then treat a sample as finished from step q_len[b] on (0: c_n = 0)."""
+    if q_len.is_cuda or q_len.numel() == 0:
+        return
+    lo, hi = int(q_len.min()), int(q_len.max())
+    if lo < 1:
+        raise RuntimeError(f"question length {lo}: every sample needs a length of at least 1 "
+                           "(pack_padded_sequence would raise: models/model.py:159-162)")
+    if hi > T:
+        raise RuntimeError(f"question length {hi} exceeds the padded question width {T} "
+                           "(pack_padded_sequence would raise: models/model.py:159-162)")
+
+
 class _VqaFunction(torch.autograd.Function):
     """Autograd node of one VqaNet.forward call.
 
@@ -312,6 +327,7 @@ class VqaNet(nn.Module):
         if not v.is_cuda:
             raise RuntimeError("dl_vqa_amd.VqaNet.forward needs CUDA (HIP) tensors; there is no CPU fallback")
         self._validate_tokens(q)
+        validate_question_lengths(q_len, q.shape[1])
         # v may be the dataset's fp16 storage format (preprocessing/preprocess_images.py:39-53): the first-block kernels read
         # it as it is (engine.py); no widened copy is made
         if v.dtype not in (torch.float32, torch.float16):

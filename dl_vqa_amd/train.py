@@ -16,6 +16,7 @@ from typing import Optional
 import torch
 
 from . import ops
+from .model import validate_question_lengths
 
 
 # ------------------------------------------------------------------ loss head
@@ -83,6 +84,7 @@ def run_batch(model, log_softmax, batch_data, max_answers, batch_divisor: Option
     q = q.to(dev, non_blocking=True)
     a_indices = a_indices.to(dev, non_blocking=True)
     a_values = a_values.to(dev, non_blocking=True)
+    validate_question_lengths(q_len, q.shape[1])       # host-resident lengths: the error pack_padded_sequence would raise
     q_len = q_len.to(dev, non_blocking=True)
     # the dataset stores fp16 features (data_preprocessing.py:174 casts them on the host, per sample): the fp16
     # batch goes over PCIe as is and the first-block kernels read it as it is (widened where their LDS patch is staged)

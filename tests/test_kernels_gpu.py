@@ -294,6 +294,35 @@ def test_convk_block_fwd_bwd(B, H, W, Ci, Co, ks, stride, chunk):
     assert ops.convk_bwd(xd, _nhwc(dy).to(DEV), amax, wk, dw, db, ks, stride, need_dx=False, chunk=chunk) is None
 
 
+def test_convk_block_chunks_at_a_north_star_sized_layer():
+    """Block 1 of the reference architecture with kernel_size 5 at 224 x 224 (110 x 110 x 64 -> 128 channels): one image's im2col
+    matrix is 72 MB, so a batch of 40 is walked in chunks of 29 + 11 images (2 GiB limit).  The per-image results must not
+    depend on the chunking (bitwise), the weight gradient only by its summation order."""
+    ops = _ops()
+    B, H, Ci, Co, ks = 40, 110, 64, 128, 5
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, H, H, Ci, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, ks, ks, generator=g) / math.sqrt(ks * ks * Ci)).to(DEV)
+    b = (torch.randn(Co, generator=g) * 0.1).to(DEV)
+    wk = ops.convk_pack_weights(w, Ci)
+    auto = ops.convk_chunk(B, H, H, Ci, Co, ks, 1)
+    assert 1 < auto < B
+    p1, a1 = ops.convk_fwd(x, wk, b, ks)
+    p2, a2 = ops.convk_fwd(x, wk, b, ks, chunk=8)
+    assert torch.equal(p1, p2) and torch.equal(a1, a2)
+    # spot check of one image against F.conv2d in float64
+    ref = F.max_pool2d(torch.relu(F.conv2d(x[B - 1:].permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu())), 2, 2)
+    check("convk fwd (last image of the last chunk)", p1[B - 1:].permute(0, 3, 1, 2), ref, 3e-6 * math.sqrt(ks * ks * Ci))
+    dp = torch.randn(p1.shape, generator=g).to(DEV)
+    dw1, db1, dw2, db2 = (torch.empty_like(w), torch.empty_like(b), torch.empty_like(w), torch.empty_like(b))
+    dx1 = ops.convk_bwd(x, dp, a1, wk, dw1, db1, ks)
+    dx2 = ops.convk_bwd(x, dp, a1, wk, dw2, db2, ks, chunk=8)
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2) and torch.equal(db1, db2)
+    check("convk wgrad across chunkings", dw1, dw2, 1e-5)
+    assert bool(torch.isfinite(dw1).all()) and float(dx1.abs().max()) > 0
+
+
 def test_nchw_to_nhwc4():
     ops = _ops()
     x = torch.randn(2, 3, 9, 11)
@@ -656,6 +685,28 @@ def test_attention_score_and_apply():
     # softmax gradients sum to zero over positions: dbx is exactly 0 in exact arithmetic
     assert float(dbx.abs().max()) < 1e-5 and float(br.grad.abs().max()) < 1e-12
     check("att dq(+)", dq, (xr.grad * (xs > 0).double()).reshape(B, P, mid).sum(1), 1e-5)
+
+
+@pytest.mark.parametrize("mid,G", [(256, 1), (512, 2), (768, 2), (1024, 2), (1024, 1), (1024, 3)])
+def test_attention_score_fwd_rows_in_flight(mid, G):
+    """fp32 x with mid a multiple of 256 (the reference's 1024) takes att_score_fwd_rows_kernel for G <= 2 (whole row + the next
+    row's loads in flight, weights in registers); G = 3 stays on the general kernel.  Against float64, and with dropout
+    against the stand-alone dropout pass on the same (seed, element) stream."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(mid + G)
+    B, P = 7, 333                                   # 2331 rows: more than one row per wave, a ragged tail
+    xs = torch.relu(torch.randn(B * P, mid, generator=g))
+    wx, bx = torch.randn(G, mid, generator=g), torch.randn(G, generator=g)
+    want = (xs.double() @ wx.double().t() + bx.double()).reshape(B, P, G).permute(0, 2, 1)
+    xd, wd, bd = xs.to(DEV), wx.to(DEV), bx.to(DEV)
+    score = ops.att_score_fwd(xd, wd, bd, B, P, 0.0, 0)
+    torch.cuda.synchronize()
+    check(f"att score rows mid={mid} G={G}", score, want, 3e-6)
+    dropped = ops.dropout(xd, 0.3, 991)
+    s_drop = ops.att_score_fwd(xd, wd, bd, B, P, 0.3, 991)
+    s_ref = ops.att_score_fwd(dropped, wd, bd, B, P, 0.0, 0)
+    torch.cuda.synchronize()
+    assert float((s_drop - s_ref).abs().max()) <= 1e-6 * float(s_ref.abs().max())
 
 
 def test_softce_loss_score_and_grad():

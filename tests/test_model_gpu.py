@@ -456,6 +456,24 @@ def test_out_of_vocabulary_token_ids_raise():
         m.check_token_ids()
 
 
+def test_bad_question_lengths_raise_like_pack_padded_sequence():
+    """models/model.py:159-162: pack_padded_sequence raises for a length of 0 or one above the padded width; the mirror raises
+    for host-resident lengths (what the data loader hands to run_batch)."""
+    from dl_vqa_amd.train import run_batch
+    g = Golden("tiny_plus")
+    m = build(tiny_cfg(g.meta), g.meta["V"], g.sd).eval()
+    v, q = g.t["v"].to(DEV), g.t["q"].to(DEV)
+    for bad in ([5, 0, 1], [5, 3, 6]):
+        with torch.no_grad(), pytest.raises(RuntimeError, match="question length"):
+            m(v, q, torch.tensor(bad))
+        batch = (g.t["v"], g.t["q"], g.t["a_idx"], g.t["a_val"], g.t["a_len"], None, torch.tensor(bad))
+        with torch.no_grad(), pytest.raises(RuntimeError, match="question length"):
+            run_batch(m, None, batch, 12)
+    with torch.no_grad():
+        y = m(v, q, g.t["q_len"])                        # valid host-resident lengths: same logits as device-resident ones
+        assert torch.equal(y, m(v, q, g.t["q_len"].to(DEV)))
+
+
 def test_cpu_tensors_are_rejected():
     cfg = tiny_cfg(dict(bidirectional=True, stride=1, do_option="+"))
     from dl_vqa_amd import VqaNet

@@ -33,6 +33,25 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _deps(src: str, seen=None) -> list:
+    """The quoted #include closure of a source (csrc/ and include/): an object is rebuilt when one of THESE changes, not when
+    any header of the library does."""
+    import re
+    seen = set() if seen is None else seen
+    out = []
+    try:
+        text = open(src).read()
+    except OSError:
+        return out
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        path = os.path.normpath(os.path.join(os.path.dirname(src), inc))
+        if path not in seen and os.path.exists(path):
+            seen.add(path)
+            out.append(path)
+            out += _deps(path, seen)
+    return out
+
+
 def build_library(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
     """Compile every .hip source for gfx950 and link the shared library. Returns its path.
     diag=True builds libvqa_hip_diag.so with -DVQA_DIAG (in-kernel s_memtime stamps; tools/ only)."""
@@ -46,7 +65,7 @@ def build_library(force: bool = False, verbose: bool = True, diag: bool = False)
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", suffix + ("_diag.o" if diag else ".o")))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, [s] + (_deps(s) or hdrs)):
             jobs.append([_hipcc()] + flags + extra + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -128,6 +128,9 @@ __device__ __forceinline__ void gemm_epilogue_mode(const EpiParams& pe, f32x16 (
             __builtin_amdgcn_raw_buffer_store_b16(epi_bf16(v), rb, (int)(o == BUF_OOB ? BUF_OOB : o >> 1),
                                                   (int)((uint32_t)dr * (ldb >> 1)), 0);
           } else {
+#ifdef VQA_EXP_NOSTORE_ALL   // timing experiments only: the epilogue's arithmetic without its store instructions
+            if (pe.M < 0)
+#endif
             buf_store4(rc, v, vo(dr), (uint32_t)dr * ldb);
           }
         }

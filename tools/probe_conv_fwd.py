@@ -1,6 +1,9 @@
-"""Probe: start-phase stagger (VQA_STAGGER, 10-ns ticks per K-step) on conv forward kernels and the v_conv forward GEMM."""
+"""Probe: isolated timings of the conv forward kernels and the v_conv forward GEMM (B = 256; PB overrides), repeated PN times.
+Used with VQA_LIB=build_var/libvqa_<variant>.so for the timing-only builds (-DVQA_EXP_NOSTORE_AM / _ALL, -DVQA_EXP_NO_STAGED_POOL;
+DESIGN 4.1).  The start-phase stagger experiment (a VQA_STAGGER knob delaying blocks 256..511) also ran through this script; the
+knob was withdrawn with the experiment."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dl_vqa_amd import ops, _lib
 
 def timeit(fn, iters=8):
@@ -25,11 +28,8 @@ M = B * P
 vn = torch.randn(M, C, device=dev); wv = torch.randn(mid, C, device=dev); qp = torch.randn(B, mid, device=dev)
 xs = torch.empty(M, mid, device=dev)
 cases.append(("v_conv_fwd", 2.0 * M * C * mid, lambda: ops.gemm(vn, wv, xs, M, mid, C, rowgroup=qp, rg_div=P, relu=True)))
-vals = [int(v) for v in os.environ.get("PV", "0,60,120,170,250,340,0").split(",")]
-for v in vals:
-    os.environ["VQA_STAGGER"] = str(v)
-    _lib.load().vqa_reload_knobs()
-    row = [f"stagger={v:4d}"]
+for rep in range(int(os.environ.get("PN", "3"))):
+    row = [f"run {rep}"]
     for name, fl, fn in cases:
         ms = timeit(fn)
         row.append(f"{name} {ms:.3f} ms {fl / ms / 1e9 / 157.3 * 100:.1f}%")

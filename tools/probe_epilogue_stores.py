@@ -1,6 +1,6 @@
 """Probe: kernels whose epilogues moved to 16-byte stores through LDS (conv forward, conv2 backward-data, the v_conv GEMMs)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dl_vqa_amd import ops, _lib
 
 def timeit(fn, iters=8):

@@ -1,6 +1,6 @@
 """Probe: the v_conv forward GEMM (M = B*676, N = 1024, K = 256) with and without its fused epilogue, persistent or not."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dl_vqa_amd import ops, _lib
 
 def timeit(fn, iters=10):

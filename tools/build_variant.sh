@@ -15,7 +15,7 @@ for k in 0 1 2 3 4 5; do
   $CC "$@" -DVQA_GEMM_PART=$k -c dl_vqa_amd/csrc/gemm.hip -o build_var/$name/gemm_p$k.o &
 done
 wait
-others=$(ls dl_vqa_amd/csrc/*.o | grep -E "/(bf16|conv_bf16|conv_patch_bf16|conv_patch_f32|gemm_tall_bf16|conv_x3|gemm_x3(_p[0-9])?)\.o$")
+others=$(ls dl_vqa_amd/csrc/*.o | grep -E "/(bf16|conv_bf16|conv_patch_bf16|conv_patch_f32|conv_generic|gemm_tall_bf16|conv_x3|gemm_x3(_p[0-9])?)\.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_var/libvqa_$name.so build_var/$name/*.o $others
 rm -rf build_var/$name
 echo build_var/libvqa_$name.so

@@ -47,11 +47,12 @@ def _worker(rank, world, port, out_dir):
         model, cfg = _make_model(seed=100 + rank)
         dp = DataParallel(model)
         assert model._seed_rank == rank and model._grad_sync is dp
-        batch = O.synthetic_batch(6, 32, 5, 40, 12, seed=9)
+        btot = 3 * world
+        batch = O.synthetic_batch(btot, 32, 5, 40, 12, seed=9)
         v, q, a_idx, a_val, _, _, q_len = shard_batch(batch, rank, world)
         assert v.shape[0] == 3
         sd = {k: p.data.clone() for k, p in model.named_parameters()}
-        _, _, grads = O.loss_and_grads(sd, cfg, v, q, q_len, a_idx, a_val, loss_scale_batch=6)
+        _, _, grads = O.loss_and_grads(sd, cfg, v, q, q_len, a_idx, a_val, loss_scale_batch=btot)
         views = model._grad_views()
         for k, g in grads.items():
             views[k].copy_(g)
@@ -64,18 +65,22 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_single_rank_on_concatenated_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_gradients_equal_single_rank_on_concatenated_batch(tmp_path, world):
+    """world_size 2 and 4 (the driver's scaling runs go to 8): every rank ends with rank 0's parameters and the gradient of
+    the concatenated batch."""
     from oracle import vqa_oracle as O
-    world, port = 2, _free_port()
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
-    r1 = torch.load(tmp_path / "rank1.pt")
-    assert torch.equal(r0["flat_param"], r1["flat_param"])          # broadcast made the replicas equal
-    assert torch.equal(r0["flat_grad"], r1["flat_grad"])            # all-reduce: same result everywhere
+    for k in range(1, world):
+        rk = torch.load(tmp_path / f"rank{k}.pt")
+        assert torch.equal(r0["flat_param"], rk["flat_param"])      # broadcast made the replicas equal
+        assert torch.equal(r0["flat_grad"], rk["flat_grad"])        # all-reduce: same result everywhere
     model, cfg = _make_model(seed=100)                               # rank 0's weights
     model._ensure_flat()
     assert torch.equal(model._flat_param, r0["flat_param"])
-    v, q, a_idx, a_val, _, _, q_len = O.synthetic_batch(6, 32, 5, 40, 12, seed=9)
+    v, q, a_idx, a_val, _, _, q_len = O.synthetic_batch(3 * world, 32, 5, 40, 12, seed=9)
     sd = {k: p.data.clone() for k, p in model.named_parameters()}
     _, _, grads = O.loss_and_grads(sd, cfg, v, q, q_len, a_idx, a_val)
     views = model._grad_views()

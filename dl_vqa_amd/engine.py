@@ -80,6 +80,9 @@ class Engine:
         # of 8 (16-byte operand rows); VQA_FC16=0 keeps them on the fp32 GEMM
         self.fc16 = (self.bf16 and os.environ.get("VQA_FC16", "1") != "0"
                      and all(d % 8 == 0 for d in (self.Q, self.mid, self.Dc, self.hid, self.A)))
+        # bf16 path: the recurrent weight gradient dW_hh = dgates^T . h (K = T * B: the largest LSTM-side product) on bf16 MFMA,
+        # operands staged as bf16, fp32 accumulation ("bf16 conv/FC + fp32 LSTM accumulate"); VQA_LSTM16=0 keeps it on the fp32 GEMM
+        self.lstm16 = self.bf16 and os.environ.get("VQA_LSTM16", "1") != "0" and self.H % 8 == 0
         if self.bf16:
             if self.L < 2 or any(ch % 64 for ch in self.channels[1:]) or self.mid % 8 or self.stride != 1:
                 raise ValueError("the bf16 path needs >= 2 conv blocks, stride 1 and channel counts that are multiples "
@@ -578,8 +581,14 @@ class Engine:
             st = ctx.lstm[d]
             dgates = st.dgates
             h_in = st.Hs[0:T] if d == 0 else st.Hs[1:T + 1]
-            ops.gemm(dgates, h_in, Gr["text.lstm.weight_hh_l0" + sfx(d)], 4 * H, H, T * B, transA=True, transB=False,
-                     lda=4 * H, ldb=H, tag=51)
+            if self.lstm16 and (T * B) % 8 == 0:
+                dg16 = ops.to_bf16(dgates.view(T * B, 4 * H))
+                h16 = ops.to_bf16(h_in.reshape(T * B, H))
+                ops.gemm_bf16(dg16, h16, Gr["text.lstm.weight_hh_l0" + sfx(d)], 4 * H, H, T * B, transA=True, transB=False,
+                              lda=4 * H, ldb=H, tag=51)
+            else:
+                ops.gemm(dgates, h_in, Gr["text.lstm.weight_hh_l0" + sfx(d)], 4 * H, H, T * B, transA=True, transB=False,
+                         lda=4 * H, ldb=H, tag=51)
             ops.gemm(dgates, ctx.x_emb, Gr["text.lstm.weight_ih_l0" + sfx(d)], 4 * H, E, T * B, transA=True,
                      transB=False, lda=4 * H, ldb=E, tag=52)
             ops.colsum(dgates, T * B, 4 * H, Gr["text.lstm.bias_ih_l0" + sfx(d)])

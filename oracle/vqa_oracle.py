@@ -151,8 +151,33 @@ def l2_normalise(v: Tensor) -> Tensor:
 # --------------------------------------------------------------------------
 # question encoder — reference models/model.py:134-166 (questionNet)
 # --------------------------------------------------------------------------
+def lstm16_ok(H: int, rows: int) -> bool:
+    """bf16 path: the recurrent weight gradient dW_hh = dgates^T . h runs on bf16 MFMA (both operands staged as bf16, fp32
+    accumulation) when the bf16 GEMM's 16-byte rows allow it; the same rule as dl_vqa_amd.engine.Engine (A/B switch
+    VQA_LSTM16=0).  The recurrence itself, the input-side products and every other LSTM gradient stay fp32."""
+    import os
+    return os.environ.get("VQA_LSTM16", "1") != "0" and H % 8 == 0 and rows % 8 == 0
+
+
+class _HhProduct(torch.autograd.Function):
+    """h . W_hh^T of one LSTM step; with `on` the WEIGHT gradient is taken from bf16-rounded operands (the HIP path stages
+    dgates and the saved h as bf16 for that one product), the gradient w.r.t. h stays fp32."""
+
+    @staticmethod
+    def forward(ctx, h, w, on):
+        ctx.save_for_backward(h, w)
+        ctx.on = on
+        return h @ w.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, w = ctx.saved_tensors
+        gw = rb(gy).t() @ rb(h) if ctx.on else gy.t() @ h
+        return gy @ w, gw, None
+
+
 def lstm_direction(x: Tensor, q_len: Tensor, w_ih: Tensor, w_hh: Tensor,
-                   b_ih: Tensor, b_hh: Tensor, reverse: bool) -> Tuple[Tensor, Tensor]:
+                   b_ih: Tensor, b_hh: Tensor, reverse: bool, whh16: bool = False) -> Tuple[Tensor, Tensor]:
     """One direction of nn.LSTM over a packed batch, as a masked loop.
 
     x [B,T,E]; sample b is updated only at steps t < q_len[b]; the reverse
@@ -167,7 +192,7 @@ def lstm_direction(x: Tensor, q_len: Tensor, w_ih: Tensor, w_hh: Tensor,
     c = x.new_zeros(B, H)
     steps = range(T - 1, -1, -1) if reverse else range(T)
     for t in steps:
-        gates = x[:, t] @ w_ih.t() + h @ w_hh.t() + b_ih + b_hh
+        gates = x[:, t] @ w_ih.t() + _HhProduct.apply(h, w_hh, whh16) + b_ih + b_hh
         i, f, g, o = gates.split(H, dim=1)
         i, f, o = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o)
         g = torch.tanh(g)
@@ -180,7 +205,7 @@ def lstm_direction(x: Tensor, q_len: Tensor, w_ih: Tensor, w_hh: Tensor,
 
 
 def question_encoder(sd: Dict[str, Tensor], q: Tensor, q_len: Tensor,
-                     bidirectional: bool = True, masks: Optional[dict] = None) -> Tensor:
+                     bidirectional: bool = True, masks: Optional[dict] = None, bf16: bool = False) -> Tensor:
     """questionNet.forward: embedding(pad 0) -> dropout -> tanh -> LSTM -> c_n.
 
     Returns [B, 2H] = [c_fwd | c_bwd]  (model.py:164-166: c_n.transpose(0,1).flatten(1)).
@@ -189,14 +214,15 @@ def question_encoder(sd: Dict[str, Tensor], q: Tensor, q_len: Tensor,
     # padding_idx=0 (model.py:138-140): row 0 is read as stored but receives no gradient
     x = torch.tanh(_drop(F.embedding(q, emb, padding_idx=0), masks, "text"))       # model.py:155-157
     outs = []
+    w16 = bf16 and lstm16_ok(sd["text.lstm.weight_hh_l0"].shape[1], x.shape[0] * x.shape[1])
     _, c = lstm_direction(x, q_len, sd["text.lstm.weight_ih_l0"], sd["text.lstm.weight_hh_l0"],
-                          sd["text.lstm.bias_ih_l0"], sd["text.lstm.bias_hh_l0"], False)
+                          sd["text.lstm.bias_ih_l0"], sd["text.lstm.bias_hh_l0"], False, w16)
     outs.append(c)
     if bidirectional:
         _, c = lstm_direction(x, q_len, sd["text.lstm.weight_ih_l0_reverse"],
                               sd["text.lstm.weight_hh_l0_reverse"],
                               sd["text.lstm.bias_ih_l0_reverse"],
-                              sd["text.lstm.bias_hh_l0_reverse"], True)
+                              sd["text.lstm.bias_hh_l0_reverse"], True, w16)
         outs.append(c)
     return torch.cat(outs, dim=1)
 
@@ -253,7 +279,7 @@ def vqa_forward(sd: Dict[str, Tensor], cfg: dict, v: Tensor, q: Tensor, q_len: T
     bf16: the bf16 path's rounding points (see rb above)."""
     img = image_encoder(sd, v, cfg["image"]["stride"], stages, masks, bf16)
     vn = l2_normalise(img)
-    qf = question_encoder(sd, q, q_len, cfg["text"]["bidirectional"], masks)
+    qf = question_encoder(sd, q, q_len, cfg["text"]["bidirectional"], masks, bf16)
     att = attention_scores(sd, vn, qf, cfg["attention"]["do_option"], masks, bf16)
     wv, probs = image_question_attention(vn, att)              # the weighted sum sees v WITHOUT attention.drop
     logits = classifier(sd, torch.cat([wv, qf], dim=1), masks, bf16)

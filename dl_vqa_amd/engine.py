@@ -80,8 +80,8 @@ class Engine:
         # of 8 (16-byte operand rows); VQA_FC16=0 keeps them on the fp32 GEMM
         self.fc16 = (self.bf16 and os.environ.get("VQA_FC16", "1") != "0"
                      and all(d % 8 == 0 for d in (self.Q, self.mid, self.Dc, self.hid, self.A)))
-        # bf16 path: the recurrent weight gradient dW_hh = dgates^T . h (K = T * B: the largest LSTM-side product) on bf16 MFMA,
-        # operands staged as bf16, fp32 accumulation ("bf16 conv/FC + fp32 LSTM accumulate"); VQA_LSTM16=0 keeps it on the fp32 GEMM
+        # bf16 path: the LSTM's non-recurrent products (xg = x . W_ih^T, dW_hh, dW_ih, dx) on bf16 MFMA, operands staged as bf16,
+        # fp32 accumulation ("bf16 conv/FC + fp32 LSTM accumulate"); the recurrence stays fp32.  VQA_LSTM16=0: all fp32
         self.lstm16 = self.bf16 and os.environ.get("VQA_LSTM16", "1") != "0" and self.H % 8 == 0
         if self.bf16:
             if self.L < 2 or any(ch % 64 for ch in self.channels[1:]) or self.mid % 8 or self.stride != 1:
@@ -111,6 +111,16 @@ class Engine:
             torch.empty(rows, cols, dtype=torch.bfloat16, device=x.device)
         ops.to_bf16(x.view(rows, cols), out=out[:rows])
         return out
+
+    @staticmethod
+    def _cols16(x: Tensor, rows: int, cols: int, cols8: int) -> Tensor:
+        """bf16 copy [rows, cols8] of the contiguous fp32 matrix x [rows, cols], columns beyond `cols` zero."""
+        x = x.reshape(rows, cols)
+        if cols8 == cols:
+            return ops.to_bf16(x)
+        t = torch.zeros(rows, cols8, dtype=torch.float32, device=x.device)
+        ops.add2d(x, cols, None, 0, t, cols8, rows, cols)
+        return ops.to_bf16(t)
 
     def _x3_layer(self, x_shape, Co) -> bool:
         """fp32x3 mode: does this conv block (NHWC input shape, output channels) run on the split kernels?"""
@@ -210,12 +220,27 @@ class Engine:
         def sfx(d):
             return "_reverse" if d else ""
 
+        # bf16 path: the LSTM's non-recurrent products on bf16 MFMA (fp32 accumulation): xg = x . W_ih^T here, dW_hh, dW_ih
+        # and dx in backward; x and W_ih staged as bf16 with the embedding width padded to a multiple of 8 (16-byte rows).
+        # The recurrence h . W_hh^T, the cells and their gradients stay fp32.  VQA_LSTM16=0: everything fp32.
+        l16 = self.lstm16 and (T * B) % 8 == 0
+        E8 = (E + 7) // 8 * 8
+        x16 = [None]
+
         def run_question_branch():
+            if l16:
+                x16[0] = self._cols16(x_emb, T * B, E, E8)
             for d in range(self.ndir):
                 xg = new(T * B, 4 * H)
-                ops.gemm(x_emb, P["text.lstm.weight_ih_l0" + sfx(d)], xg, T * B, 4 * H, E,
-                         bias1=P["text.lstm.bias_ih_l0" + sfx(d)], bias2=P["text.lstm.bias_hh_l0" + sfx(d)], tag=10)
-                lstm[d] = SimpleNamespace(gates=new(T, B, 4 * H), xg=xg, Hs=new(T + 1, B, H), Cs=new(T + 1, B, H))
+                wih16 = None
+                if l16:
+                    wih16 = self._cols16(P["text.lstm.weight_ih_l0" + sfx(d)], 4 * H, E, E8)
+                    ops.gemm_bf16(x16[0], wih16, xg, T * B, 4 * H, E8, bias1=P["text.lstm.bias_ih_l0" + sfx(d)],
+                                  bias2=P["text.lstm.bias_hh_l0" + sfx(d)], tag=10)
+                else:
+                    ops.gemm(x_emb, P["text.lstm.weight_ih_l0" + sfx(d)], xg, T * B, 4 * H, E,
+                             bias1=P["text.lstm.bias_ih_l0" + sfx(d)], bias2=P["text.lstm.bias_hh_l0" + sfx(d)], tag=10)
+                lstm[d] = SimpleNamespace(gates=new(T, B, 4 * H), xg=xg, Hs=new(T + 1, B, H), Cs=new(T + 1, B, H), wih16=wih16)
                 lstm[d].Hs[T if d else 0].zero_()         # h_0 = c_0 = 0: only the initial slot is read before
                 lstm[d].Cs[T if d else 0].zero_()         # it is written
             if fused:
@@ -413,7 +438,7 @@ class Engine:
         if not keep:
             return logits, None
         ctx = SimpleNamespace(B=B, T=T, Pn=Pn, q=q, q_len=q_len, acts=acts, idxs=idxs, wds=wds, vn=vn, norm=norm,
-                              x_emb=x_emb, lstm=lstm, v_in=v_in, v16=v16, wv16=wv16, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
+                              x_emb=x_emb, x16=x16[0], lstm=lstm, v_in=v_in, v16=v16, wv16=wv16, q_in=q_in, ld_q=ld_q, xs=xs, probs=probs,
                               c_in=c_in, h1=h1, h1d=h1d, fast0=fast0, use_pc=use_pc, fc=fc, vprime=vprime, qp=qp, p_img=p_img, p_txt=p_txt, p_att=p_att, p_cls=p_cls,
                               seed=seed, stages=dict(pooled=pooled, score=score, combined=combined))
         return logits, ctx
@@ -581,20 +606,34 @@ class Engine:
             st = ctx.lstm[d]
             dgates = st.dgates
             h_in = st.Hs[0:T] if d == 0 else st.Hs[1:T + 1]
-            if self.lstm16 and (T * B) % 8 == 0:
+            l16 = ctx.x16 is not None                # the forward's decision (bf16 path, T * B a multiple of 8)
+            if l16:
+                # one bf16 copy of dgates feeds the three products; dW_ih and dx come out E8 wide (the padded embedding
+                # width) and their first E columns are copied to where the fp32 products would have written them
+                E8 = ctx.x16.shape[1]
                 dg16 = ops.to_bf16(dgates.view(T * B, 4 * H))
                 h16 = ops.to_bf16(h_in.reshape(T * B, H))
                 ops.gemm_bf16(dg16, h16, Gr["text.lstm.weight_hh_l0" + sfx(d)], 4 * H, H, T * B, transA=True, transB=False,
                               lda=4 * H, ldb=H, tag=51)
+                dwp = Gr["text.lstm.weight_ih_l0" + sfx(d)] if E8 == E else new(4 * H, E8)
+                ops.gemm_bf16(dg16, ctx.x16, dwp, 4 * H, E8, T * B, transA=True, transB=False, lda=4 * H, ldb=E8, tag=52)
+                if E8 != E:
+                    ops.add2d(dwp, E8, None, 0, Gr["text.lstm.weight_ih_l0" + sfx(d)], E, 4 * H, E)
             else:
                 ops.gemm(dgates, h_in, Gr["text.lstm.weight_hh_l0" + sfx(d)], 4 * H, H, T * B, transA=True, transB=False,
                          lda=4 * H, ldb=H, tag=51)
-            ops.gemm(dgates, ctx.x_emb, Gr["text.lstm.weight_ih_l0" + sfx(d)], 4 * H, E, T * B, transA=True,
-                     transB=False, lda=4 * H, ldb=E, tag=52)
+                ops.gemm(dgates, ctx.x_emb, Gr["text.lstm.weight_ih_l0" + sfx(d)], 4 * H, E, T * B, transA=True,
+                         transB=False, lda=4 * H, ldb=E, tag=52)
             ops.colsum(dgates, T * B, 4 * H, Gr["text.lstm.bias_ih_l0" + sfx(d)])
             ops.add2d(Gr["text.lstm.bias_ih_l0" + sfx(d)], 4 * H, None, 0, Gr["text.lstm.bias_hh_l0" + sfx(d)], 4 * H, 1, 4 * H)
-            ops.gemm(dgates, P["text.lstm.weight_ih_l0" + sfx(d)], dx_parts[d], T * B, E, 4 * H, transB=False,
-                     lda=4 * H, ldb=E, tag=53)
+            if l16:
+                dxp = dx_parts[d] if E8 == E else new(T * B, E8)
+                ops.gemm_bf16(dg16, st.wih16, dxp, T * B, E8, 4 * H, transB=False, lda=4 * H, ldb=E8, tag=53)
+                if E8 != E:
+                    ops.add2d(dxp, E8, None, 0, dx_parts[d], E, T * B, E)
+            else:
+                ops.gemm(dgates, P["text.lstm.weight_ih_l0" + sfx(d)], dx_parts[d], T * B, E, 4 * H, transB=False,
+                         lda=4 * H, ldb=E, tag=53)
 
         # The question branch's backward runs on a side stream: BPTT, the weight gradients of every direction, the
         # embedding gradient, and from there the 'text' bucket goes to the data-parallel hook, so its all-reduce

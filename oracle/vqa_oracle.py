@@ -152,9 +152,10 @@ def l2_normalise(v: Tensor) -> Tensor:
 # question encoder — reference models/model.py:134-166 (questionNet)
 # --------------------------------------------------------------------------
 def lstm16_ok(H: int, rows: int) -> bool:
-    """bf16 path: the recurrent weight gradient dW_hh = dgates^T . h runs on bf16 MFMA (both operands staged as bf16, fp32
-    accumulation) when the bf16 GEMM's 16-byte rows allow it; the same rule as dl_vqa_amd.engine.Engine (A/B switch
-    VQA_LSTM16=0).  The recurrence itself, the input-side products and every other LSTM gradient stay fp32."""
+    """bf16 path: the LSTM's non-recurrent products -- xg = x . W_ih^T, dW_hh = dgates^T . h, dW_ih = dgates^T . x,
+    dx = dgates . W_ih -- run on bf16 MFMA (operands staged as bf16, fp32 accumulation) when the bf16 GEMM's 16-byte rows
+    allow it; the same rule as dl_vqa_amd.engine.Engine (A/B switch VQA_LSTM16=0).  The recurrence h . W_hh^T, the cells and
+    the gradient that flows back through time stay fp32."""
     import os
     return os.environ.get("VQA_LSTM16", "1") != "0" and H % 8 == 0 and rows % 8 == 0
 
@@ -192,7 +193,9 @@ def lstm_direction(x: Tensor, q_len: Tensor, w_ih: Tensor, w_hh: Tensor,
     c = x.new_zeros(B, H)
     steps = range(T - 1, -1, -1) if reverse else range(T)
     for t in steps:
-        gates = x[:, t] @ w_ih.t() + _HhProduct.apply(h, w_hh, whh16) + b_ih + b_hh
+        # bf16 path (whh16): x and W_ih staged as bf16 for xg; the rounded output gradient feeds dW_ih and dx (as _linear16)
+        xg = _rfb(F.linear(_rfb(x[:, t], fwd=True, bwd=False, on=whh16), _w16(w_ih, whh16)), fwd=False, bwd=True, on=whh16)
+        gates = xg + _HhProduct.apply(h, w_hh, whh16) + b_ih + b_hh
         i, f, g, o = gates.split(H, dim=1)
         i, f, o = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o)
         g = torch.tanh(g)

@@ -232,6 +232,56 @@ def test_bf16_module_matches_bf16_oracle(do_option, train):
     print(f"[parity-bf16] worst gradient error {worst:.3e}")
 
 
+@pytest.mark.parametrize("lstm16", ["1", "0"])
+def test_bf16_module_lstm_side_products_match_bf16_oracle(lstm16, monkeypatch):
+    """T * B a multiple of 8 (here 4 x 6): the LSTM's non-recurrent products (xg = x . W_ih^T, dW_hh, dW_ih, dx) run on bf16
+    MFMA with the embedding width padded from 20 to 24 (engine.py, VQA_LSTM16); the oracle rounds the same operands
+    (vqa_oracle._HhProduct, lstm16_ok).  The other module tests have T * B = 12 / 18 / 28 and keep these products in fp32.
+    Train mode with shared masks, both settings of the switch, the tolerances of test_bf16_module_matches_bf16_oracle."""
+    from oracle import vqa_oracle as O
+    from dl_vqa_amd import VqaNet
+    from dl_vqa_amd.train import soft_ce_loss_and_score
+    from tests.hip_masks import hip_masks
+    monkeypatch.setenv("VQA_LSTM16", lstm16)
+    cfg = bf16_cfg("+", 0.3)
+    V, B, S, T = 50, 4, 48, 6
+    torch.manual_seed(5)
+    m = VqaNet(cfg, V, compute_dtype="bf16").to(DEV).train()
+    sd = {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}
+    v, q, a_idx, a_val, _, _, ql = O.synthetic_batch(B, S, T, V, 24, seed=12)
+    torch.manual_seed(9)
+    y = m(v.to(DEV), q.to(DEV), ql.to(DEV))
+    loss, _ = soft_ce_loss_and_score(y, a_idx.to(DEV), a_val.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ctx = m._last_ctx
+    assert (ctx.x16 is not None) == (lstm16 == "1")
+    if lstm16 == "1":
+        assert ctx.x16.dtype == torch.bfloat16 and tuple(ctx.x16.shape) == (T * B, 24)
+        assert float(ctx.x16[:, 20:].float().abs().max()) == 0.0
+    masks = hip_masks(m._engine, ctx.seed, B, T, ctx.acts[-1].shape[1], DEV)
+    assert O.lstm16_ok(32, T * B) == (lstm16 == "1")
+    y_ref, loss_ref, g_ref = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks, bf16=True)
+    y_f32, _, g_f32 = O.loss_and_grads(sd, cfg, v, q, ql, a_idx, a_val, masks=masks)
+    err = float((y.detach().cpu() - y_ref).abs().max())
+    dist = float((y_f32 - y_ref).abs().max())
+    print(f"[parity-bf16] module (lstm16={lstm16}) logits |err| vs bf16 oracle {err:.3e}; bf16 vs fp32 oracle {dist:.3e}")
+    assert err < 5e-5 and err < 0.5 * dist
+    assert abs(float(loss) - float(loss_ref)) < 5e-5
+    for k, p in m.named_parameters():
+        ref = g_ref[k]
+        scale = max(float(ref.abs().max()), 1e-12)
+        if k == "attention.x_conv.bias":
+            assert float(p.grad.abs().max()) < 1e-6
+            continue
+        e = float((p.grad.cpu() - ref).abs().max()) / scale
+        d = float((g_f32[k] - ref).abs().max()) / scale
+        print(f"[parity-bf16] module (lstm16={lstm16}) grad {k}: vs bf16 oracle {e:.3e}; bf16 vs fp32 oracle {d:.3e}")
+        assert e < 2e-2, (k, e)
+        if k.startswith("text.lstm.weight") or k == "text.embedding.weight":
+            assert e < 2e-3, (k, e)      # the products this test is about: far inside the common bound
+
+
 @pytest.mark.parametrize("pconv", ["1", "0"])
 def test_bf16_module_patch_conv_path_matches_bf16_oracle(pconv, monkeypatch):
     """The bf16 module on the reference's channel counts 3/64/128/256 (small image), where blocks 1.. run on the patch
